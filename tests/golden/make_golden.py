@@ -1,0 +1,303 @@
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE.
+
+Runs only in the build container (needs /root/reference and transformers).  The
+reference's code is imported, never copied: what is stored is inputs and the
+outputs the reference computed for them.  `benchmark.py` /
+`benchmark_dynamic_schedule.py` import `loguru`, `rich`, `tqdm` at module top
+(absent here) — those three are replaced by empty stand-in modules before the
+import; nothing on the measured path uses them.
+
+    python tests/golden/make_golden.py
+
+Fixtures (SURVEY.md §8c list):
+  G1 draft_forward_<cfg>.npz   multi-cycle DFlashDraftModel.forward with cache
+  G2 argmax.npz                sample(logits, 0) incl. engineered exact ties
+  G3 accept.json               acceptance scan / commit on synthetic id pairs
+  G4 e2e_<name>.json           spec_generate / dflash_generate / _policy ids
+  G5 scheduler.json            EWMAPerformanceScheduler decision traces
+  G6 sample_t.npz              sample(logits, 0.7) under torch.manual_seed
+"""
+import json
+import os
+import sys
+import time
+import types
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+REF = "/root/reference"
+sys.path.insert(0, REF)
+
+import numpy as np
+import torch
+
+import importlib.util  # noqa: E402
+
+for name in ("loguru", "rich", "tqdm"):
+    if importlib.util.find_spec(name) is None:
+        m = types.ModuleType(name)
+        m.logger = types.SimpleNamespace(warning=print, info=print)
+        m.print = print
+        m.tqdm = lambda x, **k: x
+        sys.modules[name] = m
+
+from transformers import Qwen3Config  # noqa: E402
+from model import DFlashDraftModel, sample as ref_sample  # noqa: E402  (reference)
+import benchmark as ref_bench  # noqa: E402  (reference)
+import benchmark_dynamic_schedule as ref_dyn  # noqa: E402  (reference)
+
+import helpers as H  # noqa: E402
+from dflash_amd.config import DFlashConfig  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def ref_draft(cfg: DFlashConfig, sd: dict, dtype, attn_impl: str) -> DFlashDraftModel:
+    hf = Qwen3Config(hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
+                     num_attention_heads=cfg.num_attention_heads, num_key_value_heads=cfg.num_key_value_heads,
+                     head_dim=cfg.head_dim, intermediate_size=cfg.intermediate_size, vocab_size=cfg.vocab_size,
+                     rms_norm_eps=cfg.rms_norm_eps, max_position_embeddings=cfg.max_position_embeddings,
+                     rope_parameters={"rope_type": "default", "rope_theta": cfg.rope_theta},
+                     attention_bias=False, tie_word_embeddings=False)
+    hf.block_size = cfg.block_size
+    hf.num_target_layers = cfg.num_target_layers
+    hf.dflash_config = {"mask_token_id": cfg.mask_token_id, "target_layer_ids": list(cfg.target_layer_ids)}
+    hf._attn_implementation = attn_impl
+    # Instantiate under the default dtype, as `from_pretrained(dtype=...)` does
+    # (benchmark.py:411-416): parameters come out in `dtype` while the rotary
+    # `inv_freq` buffer stays fp32.  A blanket `.to(bf16)` would round inv_freq.
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        m = DFlashDraftModel(hf)
+    finally:
+        torch.set_default_dtype(prev)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and not missing, (missing, unexpected)
+    assert m.rotary_emb.inv_freq.dtype == torch.float32 and m.fc.weight.dtype == dtype
+    return m.eval()
+
+
+def f32(t):
+    return t.detach().to(torch.float32).cpu().numpy()
+
+
+# ---------------------------------------------------------------- G1
+def gen_draft_forward(tag, cfg, dtype, attn_impl, prompt_len, steps, seed):
+    from transformers import DynamicCache
+    sd = H.draft_weights(cfg, dtype=dtype)
+    model = ref_draft(cfg, sd, dtype, attn_impl)
+    g = torch.Generator().manual_seed(seed)
+    cache = DynamicCache()
+    out = {"prompt_len": prompt_len, "steps": np.array(steps), "dtype": str(dtype), "attn_impl": attn_impl,
+           "w_checksum": float(sum(v.float().sum() for v in sd.values()))}
+    start = prompt_len
+    ctx_rows = prompt_len
+    with torch.inference_mode():
+        for c, (bs, tau_next) in enumerate(steps):
+            th = (torch.randn(1, ctx_rows, cfg.fc_in, generator=g) * 1.5).to(dtype)
+            ne = (torch.randn(1, bs, cfg.hidden_size, generator=g) * 0.05).to(dtype)
+            pos = torch.arange(cache.get_seq_length(), start + bs).unsqueeze(0)
+            hid = model(target_hidden=th, noise_embedding=ne, position_ids=pos, past_key_values=cache,
+                        use_cache=True, is_causal=False)
+            cache.crop(start)
+            out[f"th{c}"], out[f"ne{c}"], out[f"hid{c}"] = f32(th), f32(ne), f32(hid)
+            out[f"start{c}"] = start
+            start += tau_next
+            ctx_rows = tau_next
+        # final cache content of layer 0 / last layer (post-norm, post-RoPE K; V)
+        for li in (0, cfg.num_hidden_layers - 1):
+            out[f"k_l{li}"] = f32(cache.layers[li].keys)
+            out[f"v_l{li}"] = f32(cache.layers[li].values)
+    np.savez_compressed(os.path.join(HERE, f"draft_forward_{tag}.npz"), **out)
+    print("G1", tag, "done")
+
+
+# ---------------------------------------------------------------- G2
+def gen_argmax():
+    g = torch.Generator().manual_seed(11)
+    logits = (torch.randn(1, 15, 4096 + 48, generator=g) * 2).to(torch.bfloat16)
+    # engineered exact ties: the row maximum repeated at several columns; first index must win
+    for r in range(15):
+        mx = logits[0, r].max()
+        cols = torch.randint(0, logits.shape[2], (3,), generator=g)
+        logits[0, r, cols] = mx
+    logits[0, 3, :] = 0.5                      # whole row tied -> index 0
+    logits[0, 4, -1] = 100.0                   # max in the last column
+    ids = ref_sample(logits, 0.0)
+    lf = torch.randn(1, 7, 1000, generator=g)  # fp32 logits path
+    lf[0, 2, 10] = lf[0, 2, 500] = 9.0
+    np.savez_compressed(os.path.join(HERE, "argmax.npz"), logits_bf16=f32(logits), ids_bf16=ids.numpy(),
+                        logits_f32=lf.numpy(), ids_f32=ref_sample(lf, 0.0).numpy())
+    print("G2 done")
+
+
+# ---------------------------------------------------------------- G3
+def gen_accept():
+    g = torch.Generator().manual_seed(5)
+    cases = []
+    for bs in (2, 8, 12, 16):
+        for acc_want in sorted({0, 1, bs // 2, bs - 2, bs - 1} & set(range(bs))):
+            block = torch.randint(0, 1000, (1, bs), generator=g)
+            post = torch.randint(1000, 2000, (1, bs), generator=g)      # disjoint ranges: no accidental match
+            post[0, :acc_want] = block[0, 1:acc_want + 1]
+            if acc_want + 2 < bs:                                         # a later coincidence must not count
+                post[0, acc_want + 1] = block[0, acc_want + 2]
+            # the reference's expression, model/dflash.py:258
+            acc = (block[:, 1:] == post[:, :-1]).cumprod(dim=1).sum(dim=1)[0].item()
+            start = int(torch.randint(5, 50, (1,), generator=g))
+            out = torch.full((1, start + bs + 4), 9999, dtype=torch.long)
+            out[:, start] = block[0, 0]
+            out[:, start:start + acc + 1] = block[:, :acc + 1]            # :259
+            out[:, start + acc + 1] = post[:, acc]                         # :260
+            cases.append({"bs": bs, "block": block[0].tolist(), "posterior": post[0].tolist(), "start": start,
+                          "acc": int(acc), "new_start": start + acc + 1, "out": out[0].tolist()})
+    json.dump(cases, open(os.path.join(HERE, "accept.json"), "w"))
+    print("G3", len(cases), "cases")
+
+
+# ---------------------------------------------------------------- G4
+def _scripted(dtype, attn, plan_seed, tape_seed, cfg, total):
+    base = H.tiny_target(dtype=dtype, attn_impl=attn)
+    tape = H.make_tape(total + 64, cfg.vocab_size, tape_seed, forbid=(cfg.mask_token_id,))
+    return H.ScriptedTarget(base, tape, H.make_plan(64, cfg.block_size, plan_seed))
+
+
+def gen_e2e():
+    cfg = H.tiny_cfg()
+    res = {}
+    ref_bench.cuda_time = time.perf_counter
+    clock = {"t": 0.0}
+
+    def fake_time():
+        clock["t"] += 1e-3
+        return clock["t"]
+    ref_dyn.cuda_time = fake_time
+
+    for name, dtype, attn in (("f32_eager", torch.float32, "eager"), ("bf16_sdpa", torch.bfloat16, "sdpa")):
+        sd = H.draft_weights(cfg, dtype=dtype)
+        model = ref_draft(cfg, sd, dtype, attn)
+        g = torch.Generator().manual_seed(21)
+        prompt = torch.randint(0, 2000, (1, 37), generator=g)
+
+        # (a) spec_generate, scripted acceptance, no stop ids
+        tgt = _scripted(dtype, attn, 1, 2, cfg, 37 + 90)
+        ids = model.spec_generate(target=tgt, input_ids=prompt, max_new_tokens=90, stop_token_ids=None,
+                                  temperature=0.0)
+        res[f"{name}/spec"] = {"prompt": prompt[0].tolist(), "max_new_tokens": 90, "ids": ids[0].tolist(),
+                               "verify": tgt.verify_log, "plan_seed": 1, "tape_seed": 2}
+
+        # (b) spec_generate with a stop token sitting in the tape
+        tgt = _scripted(dtype, attn, 3, 4, cfg, 37 + 90)
+        stop_id = int(tgt.tape[37 + 29])
+        ids = model.spec_generate(target=tgt, input_ids=prompt, max_new_tokens=90, stop_token_ids=[stop_id, 5],
+                                  temperature=0.0)
+        res[f"{name}/spec_stop"] = {"prompt": prompt[0].tolist(), "max_new_tokens": 90, "ids": ids[0].tolist(),
+                                    "verify": tgt.verify_log, "plan_seed": 3, "tape_seed": 4,
+                                    "stop_token_ids": [stop_id, 5]}
+
+        # (c) natural run (no scripting): random weights -> tau == 1, output == greedy AR
+        base = H.tiny_target(dtype=dtype, attn_impl=attn)
+        ids = model.spec_generate(target=base, input_ids=prompt, max_new_tokens=24, stop_token_ids=None,
+                                  temperature=0.0)
+        res[f"{name}/natural"] = {"prompt": prompt[0].tolist(), "max_new_tokens": 24, "ids": ids[0].tolist()}
+
+        # (d) harness form: benchmark.dflash_generate — bs=1 baseline, bs=12 with tail clamp, draft_steps=2
+        for key, bs, steps, mnt in (("gen_bs1", 1, 1, 12), ("gen_bs12", 12, 1, 50), ("gen_bs16", 16, 1, 61),
+                                    ("gen_steps2", 16, 2, 40)):
+            tgt = _scripted(dtype, attn, 6, 7, cfg, 37 + mnt)
+            r = ref_bench.dflash_generate(model, tgt, prompt, cfg.mask_token_id, mnt, bs, None, 0.0,
+                                          collect_profile=False, draft_steps=steps)
+            res[f"{name}/{key}"] = {"prompt": prompt[0].tolist(), "max_new_tokens": mnt, "block_size": bs,
+                                    "draft_steps": steps, "ids": r.output_ids[0].tolist(),
+                                    "acceptance_lengths": [int(a) for a in r.acceptance_lengths],
+                                    "num_output_tokens": int(r.num_output_tokens), "plan_seed": 6, "tape_seed": 7}
+
+        # (e) variable block size per cycle: benchmark_dynamic_schedule.dflash_generate_policy
+        sched = ref_dyn.EWMAPerformanceScheduler(
+            candidates=[8, 12, 16], scheduler_mode="ewma", warmup_cycles=6, ewma_alpha=0.25, switch_margin=0.03,
+            required_streak=2, cooldown_cycles=2, probe_interval=5, low_accept_threshold=0.2, low_accept_streak=3,
+            adl_rho=0.3, adl_delta=1.0, adl_k_min=8, adl_k_max=16, adl_neighborhood=4)
+        tgt = _scripted(dtype, attn, 8, 9, cfg, 37 + 120)
+        stop_id = int(tgt.tape[37 + 100])
+        r = ref_dyn.dflash_generate_policy(model=model, target=tgt, input_ids=prompt,
+                                           mask_token_id=cfg.mask_token_id, max_new_tokens=120,
+                                           stop_token_ids=[stop_id], temperature=0.0, scheduler=sched)
+        res[f"{name}/policy"] = {"prompt": prompt[0].tolist(), "max_new_tokens": 120, "stop_token_ids": [stop_id],
+                                 "ids": r.output_ids[0].tolist(),
+                                 "acceptance_lengths": [int(a) for a in r.acceptance_lengths],
+                                 "used_block_sizes": [int(b) for b in r.used_block_sizes],
+                                 "chosen_block_sizes": [int(t["chosen_block_size"]) for t in r.cycle_trace],
+                                 "l_gen": [float(t["l_gen"]) for t in r.cycle_trace],
+                                 "plan_seed": 8, "tape_seed": 9}
+        print("G4", name, "done")
+    json.dump(res, open(os.path.join(HERE, "e2e.json"), "w"))
+
+
+# ---------------------------------------------------------------- G5
+def gen_scheduler():
+    traces = []
+    g = np.random.default_rng(0)
+    param_sets = [
+        dict(candidates=[8, 12, 16], scheduler_mode="ewma", warmup_cycles=6, ewma_alpha=0.25, switch_margin=0.03,
+             required_streak=2, cooldown_cycles=2, probe_interval=5, low_accept_threshold=0.2, low_accept_streak=3,
+             adl_rho=0.3, adl_delta=1.0, adl_k_min=8, adl_k_max=16, adl_neighborhood=4),
+        dict(candidates=[16, 4, 8, 24], scheduler_mode="adl_ewma", warmup_cycles=3, ewma_alpha=0.5,
+             switch_margin=0.0, required_streak=1, cooldown_cycles=0, probe_interval=0, low_accept_threshold=0.3,
+             low_accept_streak=2, adl_rho=0.4, adl_delta=2.0, adl_k_min=4, adl_k_max=24, adl_neighborhood=8),
+        dict(candidates=[8, 16], scheduler_mode="adl_ewma", warmup_cycles=0, ewma_alpha=1.0, switch_margin=0.1,
+             required_streak=3, cooldown_cycles=4, probe_interval=3, low_accept_threshold=0.5, low_accept_streak=1,
+             adl_rho=1.0, adl_delta=0.0, adl_k_min=8, adl_k_max=16, adl_neighborhood=0),
+    ]
+    for params in param_sets:
+        s = ref_dyn.EWMAPerformanceScheduler(**params)
+        steps = []
+        for cyc in range(120):
+            chosen = s.select(cyc)
+            bs = chosen if cyc % 17 != 16 else 1       # sprinkle clamped tail cycles
+            quality = 0.15 if 40 <= cyc < 60 else 0.6   # a stretch of poor acceptance
+            tau = int(min(bs, max(1, g.binomial(bs, quality))))
+            cycle_s = float(0.04 + 0.0008 * bs + g.normal(0, 0.002))
+            l_gen = float(bs if cyc % 5 else max(1, bs // 2))
+            s.update(tau=tau, cycle_s=cycle_s, effective_bs=bs, cycle_idx=cyc, l_gen=l_gen)
+            steps.append({"chosen": int(chosen), "bs": int(bs), "tau": tau, "cycle_s": cycle_s, "l_gen": l_gen,
+                          "current": int(s.current), "cooldown_left": int(s.cooldown_left),
+                          "pending_target": int(s.pending_target), "pending_streak": int(s.pending_streak),
+                          "tau_hat": {str(k): v for k, v in s.tau_hat.items()},
+                          "score_hat": {str(k): v for k, v in s.score_hat.items()},
+                          "adl_target_k": int(s.adl_target_k), "adl_target_bs": int(s.adl_target_bs),
+                          "adl_lgen_hat": s.adl_lgen_hat, "adl_lacc_hat": s.adl_lacc_hat})
+        traces.append({"params": params, "steps": steps})
+    json.dump(traces, open(os.path.join(HERE, "scheduler.json"), "w"))
+    print("G5 done")
+
+
+# ---------------------------------------------------------------- G6
+def gen_sample_t():
+    g = torch.Generator().manual_seed(13)
+    logits = (torch.randn(1, 16, 2048, generator=g) * 3).to(torch.bfloat16)
+    torch.manual_seed(0)
+    ids = ref_sample(logits, 0.7)
+    block = torch.randint(0, 2048, (1, 16), generator=g)
+    block[0, 1:6] = ids[0, :5]
+    acc = (block[:, 1:] == ids[:, :-1]).cumprod(dim=1).sum(dim=1)[0].item()
+    np.savez_compressed(os.path.join(HERE, "sample_t.npz"), logits=f32(logits), ids=ids.numpy(),
+                        block=block.numpy(), acc=np.array(acc), temperature=np.array(0.7), seed=np.array(0))
+    print("G6 done")
+
+
+if __name__ == "__main__":
+    tiny, mid = H.tiny_cfg(), H.mid_cfg()
+    # (bs, tau_next): block size this cycle, tokens committed after it (= next cycle's ctx rows)
+    steps = [(16, 1), (16, 7), (16, 16), (12, 3), (8, 8), (16, 2)]
+    gen_draft_forward("tiny_f32_eager", tiny, torch.float32, "eager", 40, steps, 101)
+    gen_draft_forward("tiny_bf16_eager", tiny, torch.bfloat16, "eager", 40, steps, 101)
+    gen_draft_forward("tiny_bf16_sdpa", tiny, torch.bfloat16, "sdpa", 40, steps, 101)
+    gen_draft_forward("mid_bf16_sdpa", mid, torch.bfloat16, "sdpa", 300, steps, 102)
+    gen_argmax()
+    gen_accept()
+    gen_e2e()
+    gen_scheduler()
+    gen_sample_t()

@@ -1,0 +1,168 @@
+"""Shared test scaffolding: tiny configs, seeded models, scripted acceptance.
+
+Random weights make draft and target disagree on every token (tau == 1 on every
+cycle), which would leave rollback with tau > 1 untested.  The
+`ScriptedTarget` fixes the target's greedy continuation to a seeded *tape* and a
+per-cycle *plan* says how many draft tokens are made to agree with it:
+
+* under the reference / the oracle the agreement is injected at the logits level
+  by wrapping `target.lm_head` (`ScriptedLMHead`), so their loop code runs
+  unmodified;
+* under the product the same tokens are written by the `draft_token_hook` the
+  loop exposes for exactly this purpose (the draft forward, lm_head GEMM and
+  argmax still run and are checked separately on vector fixtures).
+"""
+from __future__ import annotations
+
+import os
+import sys
+from types import SimpleNamespace
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from dflash_amd.config import DFlashConfig  # noqa: E402
+from dflash_amd.synthetic import make_draft_state_dict  # noqa: E402
+from oracle.dflash_oracle import DraftConfig  # noqa: E402
+from oracle.torch_target import TorchQwen3Target  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+# Smallest shape the HIP kernels accept (K multiple of 512, head_dim 128).
+TINY = dict(hidden_size=512, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2, head_dim=128,
+            intermediate_size=1024, vocab_size=2048, num_target_layers=6, block_size=16, rope_theta=1e6,
+            mask_token_id=2047)
+TINY_TARGET = dict(vocab_size=2048, hidden_size=512, num_layers=6, num_heads=4, num_kv_heads=2, head_dim=128,
+                   intermediate_size=1024, rope_theta=1e6)
+# Mid shape: GQA group 4 like the real models, 3 taps, odd-ish sizes.
+MID = dict(hidden_size=1024, num_hidden_layers=3, num_attention_heads=8, num_key_value_heads=2, head_dim=128,
+           intermediate_size=2560, vocab_size=4096 + 16 * 7, num_target_layers=8, block_size=16, rope_theta=1e6,
+           mask_token_id=4096)
+
+
+def tiny_cfg(**over) -> DFlashConfig:
+    return DFlashConfig(**{**TINY, **over})
+
+
+def mid_cfg(**over) -> DFlashConfig:
+    return DFlashConfig(**{**MID, **over})
+
+
+def oracle_cfg(cfg: DFlashConfig, attn_impl: str = "eager") -> DraftConfig:
+    return DraftConfig(hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
+                       num_attention_heads=cfg.num_attention_heads, num_key_value_heads=cfg.num_key_value_heads,
+                       head_dim=cfg.head_dim, intermediate_size=cfg.intermediate_size,
+                       rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta, block_size=cfg.block_size,
+                       num_target_layers=cfg.num_target_layers, mask_token_id=cfg.mask_token_id,
+                       target_layer_ids=list(cfg.target_layer_ids), attn_impl=attn_impl)
+
+
+def tiny_target(dtype=torch.float32, device="cpu", seed=7, attn_impl="eager", **over) -> TorchQwen3Target:
+    return TorchQwen3Target(**{**TINY_TARGET, **over}, seed=seed, dtype=dtype, device=device, attn_impl=attn_impl)
+
+
+def draft_weights(cfg: DFlashConfig, seed=3, dtype=torch.float32, device="cpu", std=0.02) -> dict:
+    return make_draft_state_dict(cfg, seed=seed, dtype=dtype, device=device, std=std)
+
+
+def make_tape(length: int, vocab: int, seed: int, forbid=()) -> torch.Tensor:
+    g = torch.Generator().manual_seed(seed)
+    t = torch.randint(0, vocab, (length,), generator=g)
+    for f in forbid:
+        t[t == f] = (f + 1) % vocab
+    return t
+
+
+def make_plan(n: int, bs: int, seed: int) -> list[int]:
+    """Number of draft tokens that agree with the tape, per cycle: covers 0, bs-1
+    (everything accepted) and the values between."""
+    g = torch.Generator().manual_seed(seed)
+    plan = torch.randint(0, bs, (n,), generator=g).tolist()
+    plan[:4] = [0, bs - 1, 1, bs - 2][:min(4, n)]
+    return plan
+
+
+class ScriptedLMHead:
+    """Callable stand-in for `target.lm_head` used only by reference/oracle runs."""
+
+    def __init__(self, owner: "ScriptedTarget"):
+        self.owner = owner
+        self.weight = owner.base.lm_head.weight
+
+    def __call__(self, h):
+        o = self.owner
+        logits = o.base.lm_head(h).clone()
+        rows = logits.shape[1]
+        k = o.plan[min(o.cycle, len(o.plan) - 1)]
+        s = o.next_start
+        for j in range(rows):
+            tok = int(o.tape[s + 1 + j])
+            if j < k:
+                logits[0, j, tok] = 60.0
+            elif j == k:
+                logits[0, j, tok] = -60.0
+        o.cycle += 1
+        return logits
+
+
+class ScriptedTarget:
+    """Target whose greedy continuation is `tape` (absolute position -> token)."""
+
+    def __init__(self, base: TorchQwen3Target, tape: torch.Tensor, plan: list[int]):
+        self.base, self.plan = base, plan
+        self.tape = tape.to(base.device)
+        self.model = base.model
+        self.cycle = 0
+        self.next_start = None
+        self.script_lm_head = True
+        self._lm = ScriptedLMHead(self)
+        self.verify_log = []
+
+    @property
+    def lm_head(self):
+        return self._lm if self.script_lm_head else self.base.lm_head
+
+    @property
+    def device(self):
+        return self.base.device
+
+    def new_cache(self):
+        return self.base.new_cache()
+
+    def reset(self):
+        self.cycle, self.next_start, self.verify_log = 0, None, []
+
+    def __call__(self, input_ids, position_ids=None, logits_to_keep=0, **kw):
+        out = self.base(input_ids, position_ids=position_ids, logits_to_keep=logits_to_keep, **kw)
+        pos = position_ids[0]
+        if logits_to_keep:
+            pos = pos[-logits_to_keep:]
+        want = self.tape[pos + 1]
+        logits = torch.full_like(out.logits, -10.0)
+        logits[0, torch.arange(len(want), device=logits.device), want] = 10.0
+        if self.next_start is None:            # prefill
+            self.next_start = int(position_ids[0, -1]) + 1
+        else:                                   # verify: replay the loop's own accept rule
+            s = int(position_ids[0, 0])
+            acc = 0
+            n = input_ids.shape[1]
+            while acc < n - 1 and int(input_ids[0, acc + 1]) == int(self.tape[s + acc + 1]):
+                acc += 1
+            self.verify_log.append({"start": s, "bs": n, "acc": acc, "block": input_ids[0].tolist()})
+            self.next_start = s + acc + 1
+        return SimpleNamespace(logits=logits, hidden_states=out.hidden_states)
+
+    # product-side equivalent of ScriptedLMHead
+    def draft_token_hook(self, block_ids: torch.Tensor, start: int, cycle: int) -> None:
+        """block_ids [1, bs] on device, slots 1.. already hold the draft's argmax."""
+        rows = block_ids.shape[1] - 1
+        k = self.plan[min(cycle, len(self.plan) - 1)]
+        for j in range(rows):
+            tok = int(self.tape[start + 1 + j])
+            if j < k:
+                block_ids[0, j + 1] = tok
+            elif j == k and int(block_ids[0, j + 1]) == tok:
+                block_ids[0, j + 1] = (tok + 1) % self.base.cfg.vocab_size
