@@ -1,0 +1,62 @@
+"""ctypes binding of libdflash_hip.so (include/dflash_hip.h).  No fallback: if the
+library is missing or a call is rejected, this raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first, so the kernels share its HIP runtime)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libdflash_hip.so")
+
+_p, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+# name -> (restype, argtypes); mirrors include/dflash_hip.h one to one
+SIGNATURES = {
+    "dfl_version": (_i, []),
+    "dfl_last_error": (C.c_char_p, []),
+    "dfl_pack_weight": (_i, [_p, _p, _i, _i, _p]),
+    "dfl_pack_weight_gateup": (_i, [_p, _p, _p, _i, _i, _p]),
+    "dfl_set_dyn": (_i, [_p, _i, _i, _i, _i, _p]),
+    "dfl_pack_rows": (_i, [_p, _i64, _i, _i, _p, _p, _i, _p]),
+    "dfl_gemm_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p]),
+    "dfl_gemm_silu_mul": (_i, [_p, _p, _i, _i, _p, _p]),
+    "dfl_argmax_ws_bytes": (_i64, []),
+    "dfl_gemm_argmax": (_i, [_p, _p, _i, _i, _i, _i, _p, _i, _p, _p, _i, _p, _p]),
+    "dfl_norm_pack": (_i, [_p, _i, _i64, _i, _i, _p, _p, _p, _p, _p, _f, _p, _i, _p, _i, _p]),
+    "dfl_qknorm_rope_append": (_i, [_p, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _f, _p, _p, _i, _p, _p, _p, _i, _p,
+                                    _i, _i, _p]),
+    "dfl_attn_ws_bytes": (_i64, [_i, _i]),
+    "dfl_block_attn": (_i, [_p, _p, _p, _i, _i, _i, _f, _p, _i, _p, _i, _p, _p]),
+    "dfl_argmax": (_i, [_p, _i, _i, _i64, _p, _p]),
+    "dfl_accept_commit": (_i, [_p, _p, _i, _p, _i64, _p, _p, _i, _p, _p]),
+}
+
+_lib = None
+
+
+class DFlashHipError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DFlashHipError(
+                f"{LIB_PATH} not found: build it with `python -m dflash_amd.build` (hipcc, gfx950). "
+                "dflash_amd has no CPU or PyTorch fallback for its kernels.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError = header/library mismatch: fail loudly
+            fn.restype, fn.argtypes = res, args
+        if handle.dfl_version() != 1:
+            raise DFlashHipError(f"ABI version mismatch: library {handle.dfl_version()} != binding 1")
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise DFlashHipError(f"{what} failed (rc={rc}): {lib().dfl_last_error().decode()}")

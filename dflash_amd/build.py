@@ -1,0 +1,60 @@
+"""Build libdflash_hip.so (gfx950) in-tree with hipcc.  `python -m dflash_amd.build [--force]`.
+
+The .so is git-ignored but travels to the GPU box with the repo snapshot, so the
+box never needs to compile.  No GPU is needed to build (hipcc cross-compiles)."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libdflash_hip.so")
+SOURCES = ["dfl_common.hip", "gemm_skinny.hip", "rows.hip", "attn_block.hip", "accept.hip"]
+HEADERS = [os.path.join(CSRC, "dfl_common.h"), os.path.join(HERE, "..", "include", "dflash_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _stale(out: str, deps: list[str]) -> bool:
+    return not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    hipcc = _hipcc()
+    objs, jobs = [], []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(LIBDIR, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, [src] + HEADERS):
+            jobs.append([hipcc, *FLAGS, "-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print("[dflash_amd.build]", " ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+        if verbose and r.stderr.strip():
+            print(r.stderr, file=sys.stderr)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    if force or jobs or _stale(LIB, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,127 @@
+// Integer side of the hot path: greedy argmax over materialised logits (the
+// target's posterior at T=0, model/utils.py:28-29) and the acceptance scan with
+// commit, bonus token, stop test and rollback bookkeeping (model/dflash.py:258-268).
+#include "dfl_common.h"
+
+namespace {
+
+// One 256-thread block per row.  torch.argmax returns the FIRST maximal index, so
+// the reduction is on (value desc, index asc).  Values are compared as fp32 (exact
+// for bf16 inputs).
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void k_argmax(const T *__restrict__ logits, int64_t V, int64_t *__restrict__ ids) {
+  __shared__ float sv[4];
+  __shared__ int64_t si[4];
+  const T *row = logits + (int64_t)blockIdx.x * V;
+  float best = -INFINITY;
+  int64_t bi = INT64_MAX;
+  auto take = [&](float v, int64_t i) {
+    if (v > best || (v == best && i < bi) || (bi == INT64_MAX)) {
+      best = v;
+      bi = i;
+    }
+  };
+  const int64_t nvec = ((reinterpret_cast<uintptr_t>(row) % (VEC * sizeof(T))) == 0) ? V / VEC : 0;
+  typedef T vec_t __attribute__((ext_vector_type(VEC)));
+  for (int64_t c = threadIdx.x; c < nvec; c += 256) {
+    const vec_t v = *reinterpret_cast<const vec_t *>(row + c * VEC);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const float f = (float)v[j];
+      if (f > best || bi == INT64_MAX) {  // indices ascend within a thread
+        best = f;
+        bi = c * VEC + j;
+      }
+    }
+  }
+  for (int64_t i = nvec * VEC + threadIdx.x; i < V; i += 256) take((float)row[i], i);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int64_t oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) {
+      best = ov;
+      bi = oi;
+    }
+  }
+  if ((threadIdx.x & 63) == 0) {
+    sv[threadIdx.x >> 6] = best;
+    si[threadIdx.x >> 6] = bi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (sv[w] > best || (sv[w] == best && si[w] < bi)) {
+        best = sv[w];
+        bi = si[w];
+      }
+    ids[blockIdx.x] = bi;
+  }
+}
+
+// Single wavefront.  Lane i compares draft token i+1 with the target's token for
+// the same position; the accepted length is the number of trailing-zero-free ones
+// of the ballot (first mismatch by ffs), no host round trip.
+__global__ __launch_bounds__(64) void k_accept_commit(const int64_t *block_ids, const int64_t *posterior, int bs,
+                                                      int64_t *output_ids, int64_t output_len, int32_t *dyn,
+                                                      const int64_t *stop_ids, int n_stop, int32_t *result) {
+  const int i = threadIdx.x;
+  const int start = dyn[DFL_DYN_START];
+  const bool cmp = i < bs - 1;
+  const bool eq = cmp && (block_ids[i + 1] == posterior[i]);
+  const unsigned long long mism = __ballot(cmp && !eq);
+  int acc = mism ? (int)__builtin_ctzll(mism) : bs - 1;  // leading matches, 0..bs-1
+  // commit block[0..acc] at start.., then the target's own token (model/dflash.py:259-260)
+  int64_t tok = -1;
+  if (i <= acc)
+    tok = block_ids[i];
+  else if (i == acc + 1)
+    tok = posterior[acc];
+  if (i <= acc + 1 && start + i < output_len) output_ids[start + i] = tok;
+  bool hit = false;
+  if (i <= acc + 1)
+    for (int s = 0; s < n_stop; ++s) hit |= (tok == stop_ids[s]);
+  const bool any_stop = __ballot(hit) != 0ull;
+  if (i == 0) {
+    const int new_start = start + acc + 1;
+    dyn[DFL_DYN_S] = start;         // draft cache keeps rows [0, start): crop(start), :246
+    dyn[DFL_DYN_TAU] = acc + 1;     // next cycle's context rows, :263
+    dyn[DFL_DYN_POS0] = start;
+    dyn[DFL_DYN_START] = new_start; // :261
+    dyn[DFL_DYN_STOP] |= any_stop ? 1 : 0;
+    dyn[DFL_DYN_CYCLE] += 1;
+    if (result) {
+      result[0] = acc;
+      result[1] = new_start;
+      result[2] = dyn[DFL_DYN_STOP];
+      result[3] = dyn[DFL_DYN_CYCLE];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int dfl_argmax(const void *logits, int dtype, int rows, int64_t V, int64_t *ids, void *stream) {
+  DFL_REQUIRE(logits && ids, "dfl_argmax: null pointer");
+  DFL_REQUIRE(rows >= 0 && V > 0, "dfl_argmax: bad shape rows=%d V=%lld", rows, (long long)V);
+  DFL_REQUIRE(dtype == 0 || dtype == 1, "dfl_argmax: dtype must be 0 (bf16) or 1 (fp32)");
+  if (rows == 0) return DFL_OK;
+  if (dtype == 0)
+    hipLaunchKernelGGL((k_argmax<bf16_t, 8>), dim3(rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)logits, V, ids);
+  else
+    hipLaunchKernelGGL((k_argmax<float, 4>), dim3(rows), dim3(256), 0, (hipStream_t)stream, (const float *)logits, V, ids);
+  DFL_CHECK_LAUNCH("dfl_argmax");
+  return DFL_OK;
+}
+
+extern "C" int dfl_accept_commit(const int64_t *block_ids, const int64_t *posterior, int bs, int64_t *output_ids,
+                                 int64_t output_len, int32_t *dyn, const int64_t *stop_ids, int n_stop,
+                                 int32_t *result, void *stream) {
+  DFL_REQUIRE(block_ids && posterior && output_ids && dyn, "dfl_accept_commit: null pointer");
+  DFL_REQUIRE(bs >= 1 && bs <= 64, "dfl_accept_commit: bs=%d outside 1..64", bs);
+  DFL_REQUIRE(n_stop == 0 || stop_ids, "dfl_accept_commit: n_stop>0 without stop_ids");
+  hipLaunchKernelGGL(k_accept_commit, dim3(1), dim3(64), 0, (hipStream_t)stream, block_ids, posterior, bs, output_ids,
+                     output_len, dyn, stop_ids, n_stop, result);
+  DFL_CHECK_LAUNCH("dfl_accept_commit");
+  return DFL_OK;
+}

@@ -1,0 +1,55 @@
+// Shared device/host helpers for libdflash_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/dflash_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+#define DFL_WAVE 64
+
+// ---- error plumbing -------------------------------------------------------
+void dfl_set_error(const char *fmt, ...);
+
+#define DFL_REQUIRE(cond, ...)              \
+  do {                                      \
+    if (!(cond)) {                          \
+      dfl_set_error(__VA_ARGS__);           \
+      return DFL_EINVAL;                    \
+    }                                       \
+  } while (0)
+
+#define DFL_CHECK_LAUNCH(name)                                             \
+  do {                                                                     \
+    hipError_t e_ = hipGetLastError();                                     \
+    if (e_ != hipSuccess) {                                                \
+      dfl_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+      return DFL_ELAUNCH;                                                  \
+    }                                                                      \
+  } while (0)
+
+// ---- device helpers ---------------------------------------------------------
+// Round-to-nearest-even fp32 -> bf16 via the hardware convert (keeps NaN a NaN).
+__device__ __forceinline__ bf16_t f2bf(float x) { return (bf16_t)x; }
+__device__ __forceinline__ float bf2f(bf16_t x) { return (float)x; }
+// value after one bf16 rounding, kept in fp32 (where torch would have stored bf16)
+__device__ __forceinline__ float rbf(float x) { return (float)((bf16_t)x); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

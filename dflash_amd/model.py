@@ -1,0 +1,334 @@
+"""`DFlashDraftModel` — host-side mirror of the reference's draft-model operator API
+(model/dflash.py:147-277) over the gfx950 kernels.
+
+Same construction (`DFlashDraftModel(config)` + `load_state_dict` with the
+reference's key names, or `from_pretrained(dir)`), same `forward(...)` and
+`spec_generate(...)` signatures and return values, same attributes
+(`block_size`, `mask_token_id`, `target_layer_ids`, `device`).  What differs is
+underneath: weights are re-laid once into MFMA-fragment order, the draft KV
+cache is preallocated (`DFlashKVCache`, O(1) rollback instead of `torch.cat` /
+`crop`), and one cycle's draft forward + lm_head + argmax is ~50 kernel launches
+on the caller's stream with all lengths read from device memory.
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import Optional
+
+import torch
+
+from . import ops
+from .config import DFlashConfig
+from .utils import extract_context_feature, sample
+
+BF16 = torch.bfloat16
+
+
+def _rope_tables(head_dim: int, theta: float, max_pos: int, device):
+    """cos/sin rows for positions 0..max_pos-1, first half of the head only (the two
+    halves are equal).  Same arithmetic as Qwen3RotaryEmbedding.forward
+    (tf:models/qwen3/modeling_qwen3.py:125-137): fp32 product, fp32 cos/sin, cast."""
+    inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float) / head_dim))
+    pos = torch.arange(max_pos, dtype=torch.float)
+    freqs = (inv[None, :, None] @ pos[None, None, :]).transpose(1, 2)[0]  # [max_pos, head_dim/2], fp32 on the host
+    return freqs.cos().to(BF16).to(device).contiguous(), freqs.sin().to(BF16).to(device).contiguous()
+
+
+class DFlashKVCache:
+    """Preallocated draft KV cache: post-norm, post-RoPE K and V of the committed
+    context rows.  Offers the two methods the reference loop calls
+    on its DynamicCache (`get_seq_length`, `crop`, model/dflash.py:241,246); crop is
+    a counter update."""
+
+    def __init__(self, cfg: DFlashConfig, max_rows: int, device):
+        self.cfg = cfg
+        self.max_rows = int(max_rows)
+        L, kv = cfg.num_hidden_layers, cfg.num_key_value_heads
+        self.k = torch.zeros(L, kv, self.max_rows, cfg.head_dim, dtype=BF16, device=device)
+        self.v = torch.zeros_like(self.k)
+        self.dyn = torch.zeros(8, dtype=torch.int32, device=device)
+        self.length = 0
+
+    def get_seq_length(self, layer_idx: int = 0) -> int:
+        return self.length
+
+    def crop(self, max_length: int) -> None:
+        if 0 < max_length < self.length:  # legacy positive form = absolute length (tf:cache_utils.py:169-180)
+            self.length = int(max_length)
+        elif max_length < 0:
+            self.length = max(0, self.length + int(max_length))
+
+
+class DFlashDraftModel:
+    def __init__(self, config, device=None):
+        self.config = DFlashConfig.from_any(config)
+        c = self.config
+        if c.head_dim != 128:
+            raise NotImplementedError("the gfx950 kernels are built for head_dim == 128")
+        if c.hidden_size % 32 or c.intermediate_size % 32 or c.vocab_size % 16:
+            raise NotImplementedError("need hidden/intermediate % 32 == 0 and vocab % 16 == 0")
+        if c.hidden_size // 32 > 128:
+            raise NotImplementedError("hidden_size > 4096 needs the split-K activation path")
+        self.block_size = c.block_size
+        self.mask_token_id = c.mask_token_id
+        self.target_layer_ids = list(c.target_layer_ids)
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.dtype = BF16
+        self.w: Optional[dict] = None
+        self._ws = None
+        self._lm_head_cache = {}
+        self._rope = None
+
+    # ------------------------------------------------------------------ weights
+    def eval(self):
+        return self
+
+    def load_state_dict(self, sd: dict, strict: bool = True):
+        """Takes the reference module's state dict (SURVEY.md §8b key names), moves
+        each tensor to the GPU in bf16 and re-lays the matrices for streaming."""
+        c = self.config
+        want = c.state_dict_shapes()
+        missing = [k for k in want if k not in sd]
+        unexpected = [k for k in sd if k not in want and "rotary_emb" not in k]
+        if strict and (missing or unexpected):
+            raise KeyError(f"load_state_dict: missing={missing[:4]}... unexpected={unexpected[:4]}...")
+        for k, shape in want.items():
+            if k in sd and tuple(sd[k].shape) != tuple(shape):
+                raise ValueError(f"{k}: shape {tuple(sd[k].shape)} != {tuple(shape)}")
+
+        def dev(name):
+            return sd[name].to(device=self.device, dtype=BF16).contiguous()
+
+        w = {"fc": ops.pack_weight(dev("fc.weight")), "hidden_norm": dev("hidden_norm.weight"),
+             "norm": dev("norm.weight"), "layers": []}
+        for i in range(c.num_hidden_layers):
+            p = f"layers.{i}."
+            qkv = torch.cat([dev(p + "self_attn.q_proj.weight"), dev(p + "self_attn.k_proj.weight"),
+                             dev(p + "self_attn.v_proj.weight")], dim=0)
+            w["layers"].append({
+                "qkv": ops.pack_weight(qkv),
+                "o": ops.pack_weight(dev(p + "self_attn.o_proj.weight")),
+                "gu": ops.pack_weight_gateup(dev(p + "mlp.gate_proj.weight"), dev(p + "mlp.up_proj.weight")),
+                "down": ops.pack_weight(dev(p + "mlp.down_proj.weight")),
+                "q_norm": dev(p + "self_attn.q_norm.weight"), "k_norm": dev(p + "self_attn.k_norm.weight"),
+                "ln1": dev(p + "input_layernorm.weight"), "ln2": dev(p + "post_attention_layernorm.weight"),
+            })
+            del qkv
+        torch.cuda.synchronize(self.device)
+        self.w = w
+        return self
+
+    @classmethod
+    def from_pretrained(cls, path: str, device=None, **_):
+        """HF checkpoint directory: config.json (+ block_size / num_target_layers /
+        dflash_config, model/dflash.py:157,162-163) and *.safetensors shards."""
+        from safetensors.torch import load_file
+        with open(os.path.join(path, "config.json")) as f:
+            cfg = json.load(f)
+        model = cls(cfg, device=device)
+        sd = {}
+        for fn in sorted(os.listdir(path)):
+            if fn.endswith(".safetensors"):
+                sd.update(load_file(os.path.join(path, fn)))
+        sd = {k[len("model."):] if k.startswith("model.") and k[6:] in model.config.state_dict_shapes() else k: v
+              for k, v in sd.items()}
+        return model.load_state_dict(sd)
+
+    # ------------------------------------------------------------------ scratch
+    def _workspace(self):
+        if self._ws is None:
+            c, d = self.config, self.device
+            H, I = c.hidden_size, c.intermediate_size
+            nqkv = c.q_dim + 2 * c.kv_dim
+            self.ks_fc = ops.min_ksplit(c.fc_in, 1)
+            self.ks_qkv = ops.min_ksplit(H, 2)
+            self.ks_o = ops.min_ksplit(c.q_dim, 1)
+            self.ks_down = ops.min_ksplit(I, 1)
+            self.ks_kv = ops.min_ksplit(H, 1)
+            npart = max(self.ks_fc * 16 * H, self.ks_qkv * 32 * nqkv, self.ks_o * 16 * H, self.ks_down * 16 * H,
+                        self.ks_kv * 16 * 2 * c.kv_dim)
+            self.max_splits = 32
+            self._ws = dict(
+                th_frag=torch.zeros(16 * c.fc_in, dtype=BF16, device=d),
+                ctx_frag=torch.zeros(16 * H, dtype=BF16, device=d),
+                xn_frag=torch.zeros(16 * H, dtype=BF16, device=d),
+                attn_frag=torch.zeros(16 * c.q_dim, dtype=BF16, device=d),
+                act_frag=torch.zeros(16 * I, dtype=BF16, device=d),
+                h=torch.zeros(16, H, dtype=BF16, device=d),
+                q_rot=torch.zeros(c.num_attention_heads, 16, 128, dtype=BF16, device=d),
+                part=torch.zeros(npart, dtype=torch.float32, device=d),
+                attn_ws=ops.attn_ws(c.num_attention_heads, self.max_splits, d),
+                argmax_ws=ops.argmax_ws(d),
+                ids16=torch.zeros(16, dtype=torch.int64, device=d),
+            )
+        return self._ws
+
+    def _rope_tab(self, need: int):
+        if self._rope is None or self._rope[0].shape[0] < need:
+            n = max(need, 4096)
+            n = 1 << (n - 1).bit_length()
+            self._rope = _rope_tables(self.config.head_dim, self.config.rope_theta, n, self.device)
+        return self._rope
+
+    def new_cache(self, max_rows: int) -> DFlashKVCache:
+        return DFlashKVCache(self.config, max_rows, self.device)
+
+    def packed_lm_head(self, lm_head) -> torch.Tensor:
+        """The target's lm_head weight [V, H] in streaming layout, packed once per
+        weight tensor (keyed on its storage) and kept on the GPU."""
+        wt = lm_head.weight if hasattr(lm_head, "weight") else lm_head
+        key = (wt.data_ptr(), tuple(wt.shape), wt._version)
+        if key not in self._lm_head_cache:
+            self._lm_head_cache.clear()
+            self._lm_head_cache[key] = ops.pack_weight(wt.detach().to(device=self.device, dtype=BF16).contiguous())
+        return self._lm_head_cache[key]
+
+    # ------------------------------------------------------------------ kernels
+    def _ctx_rows(self, th_rows: torch.Tensor, n: int, dyn, dyn_word: Optional[int]):
+        """taps [n<=16, fc_in] -> fc -> hidden_norm -> ctx_frag (model/dflash.py:177)."""
+        c, ws, w = self.config, self._workspace(), self.w
+        ops.pack_rows(th_rows, n, ws["th_frag"], dyn if dyn_word is not None else None, dyn_word or 0)
+        ops.gemm_f32(w["fc"], ws["th_frag"], None, 1, c.hidden_size, c.fc_in, self.ks_fc, ws["part"])
+        ops.norm_pack(norm_w=w["hidden_norm"], frag=ws["ctx_frag"], H=c.hidden_size, eps=c.rms_norm_eps,
+                      part=ws["part"], nsplit=self.ks_fc, part_split=16 * c.hidden_size, ldp=c.hidden_size,
+                      dyn=dyn if dyn_word is not None else None, dyn_word=dyn_word or 0)
+
+    def prefill_context(self, cache: DFlashKVCache, target_hidden: torch.Tensor, pos0: int) -> None:
+        """Append K/V of `target_hidden` rows (context only, no block) to the cache at
+        rows/positions cache.length.., in 16-row groups.  Cycle 0 of the reference
+        projects the P prompt rows together with the first block (model/dflash.py:73-85);
+        K/V rows are row-independent, so doing them first is the same arithmetic."""
+        c, ws, w = self.config, self._workspace(), self.w
+        th = target_hidden.reshape(-1, c.fc_in)
+        if th.dtype != BF16:
+            raise TypeError("target_hidden must be bf16")
+        n = th.shape[0]
+        S = cache.length
+        if S + n > cache.max_rows:
+            raise ValueError("draft KV cache too small")
+        cos, sin = self._rope_tab(pos0 + n + 64)
+        ops.set_dyn(cache.dyn, S, 0, 0, pos0)
+        nkv2 = 2 * c.kv_dim
+        for g0 in range(0, n, 16):
+            rows = min(16, n - g0)
+            self._ctx_rows(th[g0:g0 + rows], rows, None, None)
+            for i, lw in enumerate(w["layers"]):
+                # k,v column tiles only: the packed qkv weight is tile-major, q tiles first
+                kv_wp = lw["qkv"][c.q_dim * c.hidden_size:]
+                ops.gemm_f32(kv_wp, ws["ctx_frag"], None, 1, nkv2, c.hidden_size, self.ks_kv, ws["part"])
+                ops.qknorm_rope_append(qkv=ws["part"], nsplit=self.ks_kv, split_stride=16 * nkv2, ld=nkv2, q_col=-1,
+                                       k_col=0, v_col=c.kv_dim, ctx_row0=0, blk_row0=-1,
+                                       n_q=c.num_attention_heads, n_kv=c.num_key_value_heads, q_norm_w=lw["q_norm"],
+                                       k_norm_w=lw["k_norm"], eps=c.rms_norm_eps, cos_tab=cos, sin_tab=sin,
+                                       q_out=None, kcache=cache.k[i], vcache=cache.v[i], dyn=cache.dyn,
+                                       ctx_rows_override=rows, row_base=g0)
+        cache.length = S + n
+
+    def draft_block(self, cache: DFlashKVCache, *, th_rows: Optional[torch.Tensor], tau: int, bs: int, pos0: int,
+                    block_ids: Optional[torch.Tensor] = None, embed: Optional[torch.Tensor] = None,
+                    noise: Optional[torch.Tensor] = None, append: bool = True) -> torch.Tensor:
+        """One draft forward over the block (model/dflash.py:166-190 for ctx <= 16 rows).
+        Context rows `th_rows` [tau, fc_in] and the block (token ids + embedding table,
+        or a ready `noise` [bs, H]) -> final-normed hidden as frag16 (returned buffer is
+        scratch, valid until the next call).  K/V of tau+bs rows are written at cache
+        rows S.. ; `append` advances the host length by tau (the block rows are
+        dropped again, as crop(start) does at :246)."""
+        c, ws, w = self.config, self._workspace(), self.w
+        if bs < 1 or bs > 16 or tau < 0 or tau > 16:
+            raise ValueError(f"bs={bs} / tau={tau}: the kernels take 1..16 block rows and 0..16 context rows")
+        S = cache.length
+        if S + tau + bs > cache.max_rows:
+            raise ValueError("draft KV cache too small")
+        H, I = c.hidden_size, c.intermediate_size
+        nqkv = c.q_dim + 2 * c.kv_dim
+        cos, sin = self._rope_tab(pos0 + tau + bs + 64)
+        dyn = cache.dyn
+        ops.set_dyn(dyn, S, tau, bs, pos0)
+        if tau > 0:
+            self._ctx_rows(th_rows, tau, dyn, ops.DYN_TAU)
+        else:
+            ws["ctx_frag"].zero_()
+        L = w["layers"]
+        if noise is not None:
+            ops.norm_pack(norm_w=L[0]["ln1"], frag=ws["xn_frag"], H=H, eps=c.rms_norm_eps, resid_in=noise,
+                          h_out=ws["h"], dyn=dyn, dyn_word=ops.DYN_BS)
+        else:
+            ops.norm_pack(norm_w=L[0]["ln1"], frag=ws["xn_frag"], H=H, eps=c.rms_norm_eps, embed=embed,
+                          ids=block_ids, h_out=ws["h"], dyn=dyn, dyn_word=ops.DYN_BS)
+        for i, lw in enumerate(L):
+            ops.gemm_f32(lw["qkv"], ws["ctx_frag"], ws["xn_frag"], 2, nqkv, H, self.ks_qkv, ws["part"])
+            ops.qknorm_rope_append(qkv=ws["part"], nsplit=self.ks_qkv, split_stride=32 * nqkv, ld=nqkv, q_col=0,
+                                   k_col=c.q_dim, v_col=c.q_dim + c.kv_dim, ctx_row0=0, blk_row0=16,
+                                   n_q=c.num_attention_heads, n_kv=c.num_key_value_heads, q_norm_w=lw["q_norm"],
+                                   k_norm_w=lw["k_norm"], eps=c.rms_norm_eps, cos_tab=cos, sin_tab=sin,
+                                   q_out=ws["q_rot"], kcache=cache.k[i], vcache=cache.v[i], dyn=dyn)
+            ops.block_attn(q=ws["q_rot"], kcache=cache.k[i], vcache=cache.v[i], n_q=c.num_attention_heads,
+                           n_kv=c.num_key_value_heads, scale=c.head_dim ** -0.5, dyn=dyn, kv_len_max=S + tau + bs,
+                           ws=ws["attn_ws"], max_splits=self.max_splits, out_frag=ws["attn_frag"])
+            ops.gemm_f32(lw["o"], ws["attn_frag"], None, 1, H, c.q_dim, self.ks_o, ws["part"])
+            ops.norm_pack(norm_w=lw["ln2"], frag=ws["xn_frag"], H=H, eps=c.rms_norm_eps, part=ws["part"],
+                          nsplit=self.ks_o, part_split=16 * H, ldp=H, resid_in=ws["h"], h_out=ws["h"], dyn=dyn,
+                          dyn_word=ops.DYN_BS)
+            ops.gemm_silu_mul(lw["gu"], ws["xn_frag"], I, H, ws["act_frag"])
+            ops.gemm_f32(lw["down"], ws["act_frag"], None, 1, H, I, self.ks_down, ws["part"])
+            nxt = L[i + 1]["ln1"] if i + 1 < len(L) else w["norm"]
+            ops.norm_pack(norm_w=nxt, frag=ws["xn_frag"], H=H, eps=c.rms_norm_eps, part=ws["part"],
+                          nsplit=self.ks_down, part_split=16 * H, ldp=H, resid_in=ws["h"], h_out=ws["h"], dyn=dyn,
+                          dyn_word=ops.DYN_BS)
+        if append:
+            cache.length = S + tau
+        return ws["xn_frag"]
+
+    def draft_tokens(self, hid_frag: torch.Tensor, lm_head_wp: torch.Tensor, bs: int, block_ids: torch.Tensor,
+                     logits: Optional[torch.Tensor] = None) -> None:
+        """block_ids[1:bs] <- argmax(lm_head(hidden[1:bs])) (model/dflash.py:238,245,247)."""
+        c, ws = self.config, self._workspace()
+        ops.gemm_argmax(lm_head_wp, hid_frag, c.vocab_size, c.hidden_size, 1, bs - 1, ws["argmax_ws"], block_ids, 1,
+                        logits=logits)
+
+    # ------------------------------------------------------------------ reference API
+    @torch.inference_mode()
+    def forward(self, position_ids: torch.LongTensor, attention_mask=None, noise_embedding=None, target_hidden=None,
+                past_key_values: Optional[DFlashKVCache] = None, use_cache: bool = False, **kwargs) -> torch.Tensor:
+        """model/dflash.py:166-190: returns final-normed hidden states [1, q_len, H]
+        (not logits).  `past_key_values` is a `DFlashKVCache` (`model.new_cache(n)`);
+        as in the reference the K/V of context AND block rows are appended and the
+        caller crops the block rows away.  `position_ids` must be the contiguous
+        range the reference passes (`arange(cache_len, start + q_len)`)."""
+        if self.w is None:
+            raise RuntimeError("weights not loaded")
+        if attention_mask is not None:
+            raise NotImplementedError("the draft attends without a mask (is_causal=False, attention_mask=None)")
+        c = self.config
+        if noise_embedding.shape[0] != 1:
+            raise NotImplementedError("batch = 1 by construction (SURVEY.md §1)")
+        q_len, ctx = noise_embedding.shape[1], target_hidden.shape[1]
+        pos0 = int(position_ids[0, 0])
+        if position_ids.shape[1] != ctx + q_len:
+            raise ValueError("position_ids must cover context + block rows")
+        cache = past_key_values if past_key_values is not None else self.new_cache(ctx + q_len)
+        if past_key_values is None:
+            cache.length = 0
+        th = target_hidden[0].to(BF16)
+        head = max(0, ctx - 16) if ctx > 16 else 0
+        if head:
+            self.prefill_context(cache, th[:head], pos0)
+        tau = ctx - head
+        frag = self.draft_block(cache, th_rows=th[head:].contiguous() if tau else None, tau=tau, bs=q_len,
+                                pos0=pos0 + head, noise=noise_embedding[0].to(BF16).contiguous())
+        cache.length += q_len  # the reference's cache holds the block rows until crop()
+        H = c.hidden_size
+        return frag.view(H // 8, 16, 8).permute(1, 0, 2).reshape(16, H)[:q_len].unsqueeze(0).clone()
+
+    __call__ = forward
+
+    @torch.inference_mode()
+    def spec_generate(self, target, input_ids: torch.LongTensor, max_new_tokens: int, stop_token_ids,
+                      temperature: float, draft_token_hook=None) -> torch.LongTensor:
+        """model/dflash.py:192-277."""
+        from .generate import run_decode
+        r = run_decode(self, target, input_ids, mask_token_id=self.mask_token_id, max_new_tokens=max_new_tokens,
+                       block_size=self.block_size, stop_token_ids=stop_token_ids, temperature=temperature,
+                       clamp_tail=False, draft_token_hook=draft_token_hook)
+        return r.output_ids

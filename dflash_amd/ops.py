@@ -1,0 +1,146 @@
+"""torch-tensor wrappers over the C-ABI (one function per entry point).
+
+torch owns device memory and the stream; these wrappers only validate and pass
+raw pointers.  Everything raises on a non-CUDA tensor — there is no host path.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from ._lib import check, lib
+
+BF16, F32, I32, I64 = torch.bfloat16, torch.float32, torch.int32, torch.int64
+DYN_S, DYN_TAU, DYN_BS, DYN_POS0, DYN_START, DYN_STOP, DYN_CYCLE = range(7)
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor], dtype=None, name="tensor") -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"dflash_amd: {name} must be a GPU tensor (got {t.device}); there is no CPU path")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"dflash_amd: {name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"dflash_amd: {name} must be contiguous")
+    return t.data_ptr()
+
+
+# ---- one-time packing -----------------------------------------------------
+def pack_weight(w: torch.Tensor) -> torch.Tensor:
+    """[N, K] bf16 row-major -> packed weight (flat bf16 tensor of N*K)."""
+    n, k = w.shape
+    out = torch.empty(n * k, dtype=BF16, device=w.device)
+    check(lib().dfl_pack_weight(_p(w, BF16, "w"), _p(out), n, k, _stream()), "dfl_pack_weight")
+    return out
+
+
+def pack_weight_gateup(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
+    i, k = gate.shape
+    assert up.shape == gate.shape
+    out = torch.empty(2 * i * k, dtype=BF16, device=gate.device)
+    check(lib().dfl_pack_weight_gateup(_p(gate, BF16, "gate"), _p(up, BF16, "up"), _p(out), i, k, _stream()),
+          "dfl_pack_weight_gateup")
+    return out
+
+
+# ---- per-cycle ------------------------------------------------------------------
+def set_dyn(dyn: torch.Tensor, S: int, tau: int, bs: int, pos0: int) -> None:
+    check(lib().dfl_set_dyn(_p(dyn, I32, "dyn"), S, tau, bs, pos0, _stream()), "dfl_set_dyn")
+
+
+def pack_rows(x: torch.Tensor, rows: int, out_frag: torch.Tensor, dyn=None, dyn_word=0) -> None:
+    """x: [rows(+), K] bf16 with unit inner stride -> frag16 (out_frag has 16*K elements)."""
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == BF16 and x.is_cuda
+    k = x.shape[1]
+    assert out_frag.numel() >= 16 * k
+    check(lib().dfl_pack_rows(x.data_ptr(), x.stride(0), rows, k, _p(out_frag, BF16, "out_frag"),
+                              _p(dyn, I32, "dyn"), dyn_word, _stream()), "dfl_pack_rows")
+
+
+def gemm_f32(wp, xf0, xf1, mt: int, N: int, K: int, ksplit: int, out: torch.Tensor) -> None:
+    assert out.numel() >= ksplit * mt * 16 * N
+    check(lib().dfl_gemm_f32(_p(wp, BF16, "wp"), _p(xf0, BF16, "xf0"), _p(xf1, BF16, "xf1"), mt, N, K, ksplit,
+                             _p(out, F32, "out"), _stream()), "dfl_gemm_f32")
+
+
+def min_ksplit(K: int, mt: int) -> int:
+    per = 16 * (8 if mt == 1 else 4) * 32
+    return (K + per - 1) // per
+
+
+def gemm_silu_mul(wp_gu, xf, I: int, K: int, act_frag: torch.Tensor) -> None:
+    assert act_frag.numel() >= 16 * I
+    check(lib().dfl_gemm_silu_mul(_p(wp_gu, BF16, "wp_gu"), _p(xf, BF16, "xf"), I, K, _p(act_frag, BF16, "act"),
+                                  _stream()), "dfl_gemm_silu_mul")
+
+
+def argmax_ws(device) -> torch.Tensor:
+    return torch.empty(lib().dfl_argmax_ws_bytes(), dtype=torch.uint8, device=device)
+
+
+def gemm_argmax(wp, xf, V: int, K: int, row0: int, nrows: int, ws, out_ids: torch.Tensor, out_off: int = 0,
+                dyn=None, nrows_dyn_word: int = -1, logits: Optional[torch.Tensor] = None) -> None:
+    if logits is not None:
+        assert logits.numel() >= 16 * V
+    check(lib().dfl_gemm_argmax(_p(wp, BF16, "wp"), _p(xf, BF16, "xf"), V, K, row0, nrows, _p(dyn, I32, "dyn"),
+                                nrows_dyn_word, _p(ws), _p(out_ids, I64, "out_ids"), out_off,
+                                _p(logits, BF16, "logits"), _stream()), "dfl_gemm_argmax")
+
+
+def norm_pack(*, norm_w, frag, H: int, eps: float, part=None, nsplit=0, part_split=0, ldp=0, row_off=0,
+              resid_in=None, embed=None, ids=None, h_out=None, dyn=None, dyn_word=0) -> None:
+    check(lib().dfl_norm_pack(_p(part, F32, "part"), nsplit, part_split, ldp, row_off, _p(resid_in, BF16, "resid_in"),
+                              _p(embed, BF16, "embed"), _p(ids, I64, "ids"), _p(h_out, BF16, "h_out"),
+                              _p(norm_w, BF16, "norm_w"), eps, _p(frag, BF16, "frag"), H, _p(dyn, I32, "dyn"),
+                              dyn_word, _stream()), "dfl_norm_pack")
+
+
+def qknorm_rope_append(*, qkv, nsplit, split_stride, ld, q_col, k_col, v_col, ctx_row0, blk_row0, n_q, n_kv,
+                       q_norm_w, k_norm_w, eps, cos_tab, sin_tab, q_out, kcache, vcache, dyn,
+                       ctx_rows_override=-1, row_base=0) -> None:
+    assert kcache.shape == vcache.shape and kcache.dim() == 3 and kcache.shape[2] == 128
+    check(lib().dfl_qknorm_rope_append(
+        _p(qkv, F32, "qkv"), nsplit, split_stride, ld, q_col, k_col, v_col, ctx_row0, blk_row0, n_q, n_kv,
+        _p(q_norm_w, BF16, "q_norm_w"), _p(k_norm_w, BF16, "k_norm_w"), eps, _p(cos_tab, BF16, "cos"),
+        _p(sin_tab, BF16, "sin"), cos_tab.shape[0], _p(q_out, BF16, "q_out"), _p(kcache, BF16, "kcache"),
+        _p(vcache, BF16, "vcache"), kcache.shape[1], _p(dyn, I32, "dyn"), ctx_rows_override, row_base, _stream()),
+        "dfl_qknorm_rope_append")
+
+
+def attn_ws(n_q: int, max_splits: int, device) -> torch.Tensor:
+    return torch.empty(lib().dfl_attn_ws_bytes(n_q, max_splits), dtype=torch.uint8, device=device)
+
+
+def block_attn(*, q, kcache, vcache, n_q, n_kv, scale, dyn, kv_len_max, ws, max_splits, out_frag) -> None:
+    check(lib().dfl_block_attn(_p(q, BF16, "q"), _p(kcache, BF16, "kcache"), _p(vcache, BF16, "vcache"),
+                               kcache.shape[1], n_q, n_kv, scale, _p(dyn, I32, "dyn"), kv_len_max, _p(ws),
+                               max_splits, _p(out_frag, BF16, "out_frag"), _stream()), "dfl_block_attn")
+
+
+def argmax(logits: torch.Tensor) -> torch.Tensor:
+    """First-max-index argmax over the last axis, int64 (model/utils.py:28-29)."""
+    if logits.dtype not in (BF16, F32):
+        raise TypeError(f"dflash_amd.argmax: bf16 or fp32 logits, got {logits.dtype}")
+    x = logits.contiguous()
+    v = x.shape[-1]
+    rows = x.numel() // v
+    out = torch.empty(x.shape[:-1], dtype=I64, device=x.device)
+    check(lib().dfl_argmax(_p(x), 0 if x.dtype == BF16 else 1, rows, v, _p(out), _stream()), "dfl_argmax")
+    return out
+
+
+def accept_commit(block_ids, posterior, bs: int, output_ids, dyn, stop_ids=None, result=None) -> None:
+    n_stop = 0 if stop_ids is None else stop_ids.numel()
+    if result is not None:
+        assert result.numel() >= 4
+    check(lib().dfl_accept_commit(_p(block_ids, I64, "block_ids"), _p(posterior, I64, "posterior"), bs,
+                                  _p(output_ids, I64, "output_ids"), output_ids.numel(), _p(dyn, I32, "dyn"),
+                                  _p(stop_ids, I64, "stop_ids") if n_stop else None, n_stop, _p(result, I32, "result"),
+                                  _stream()),
+          "dfl_accept_commit")

@@ -1,0 +1,164 @@
+/*
+ * dflash_hip.h — C ABI of libdflash_hip.so: the MI355X (gfx950) kernels behind the
+ * DFlash block-diffusion speculative-decoding hot path.
+ *
+ * Drop-in boundary: the reference has no FFI — its hot path is
+ * Python calling torch/transformers ops.  Each entry point below replaces the
+ * torch op sequence at the cited reference lines (paths relative to the reference
+ * repo; `tf:` = transformers 5.15.0).  The Python mirror of the reference's
+ * operator API (dflash_amd.DFlashDraftModel.forward / spec_generate, dflash_generate,
+ * dflash_generate_policy) binds these with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer into caller-owned memory (torch storage)
+ *    unless named host_*; the library allocates nothing and keeps no state except
+ *    the thread-local last-error string;
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only
+ *    enqueue work, never synchronise, and are capturable into a hipGraph;
+ *  - return 0 on success, a negative DFL_E* code on a rejected argument or a
+ *    failed launch; dfl_last_error() gives the text;
+ *  - bf16 storage everywhere, fp32 accumulation; ids are int64 (torch.long).
+ *
+ * Device layouts (MI355X-first)
+ *  - "packed weight": a row-major [N][K] bf16 nn.Linear weight re-laid as
+ *    [N/16][K/32][64 lanes][8] so that one wave-wide 16-B load is one MFMA
+ *    16x16x32 A-operand fragment and a column tile streams as one contiguous run;
+ *  - "frag16 activations": up to 16 rows x K bf16 stored as [K/8][16][8], i.e. the
+ *    matching MFMA B-operand fragments, written directly by the producing kernel;
+ *  - "dyn": int32[8] per request on the device: {S, tau, bs, pos0, ...} — draft
+ *    cache length before this cycle, context rows, block rows, absolute position
+ *    of the first context row.  Kernels read lengths from it so that one captured
+ *    graph serves every cycle.
+ */
+#ifndef DFLASH_HIP_H
+#define DFLASH_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DFL_ABI_VERSION 1
+
+#define DFL_OK 0
+#define DFL_EINVAL (-22)   /* bad shape / alignment / null pointer */
+#define DFL_ELAUNCH (-5)   /* hipLaunch failed (text in dfl_last_error) */
+
+#define DFL_DYN_WORDS 8
+#define DFL_DYN_S 0        /* rows already in the draft KV cache               */
+#define DFL_DYN_TAU 1      /* context rows appended this cycle (prev acc+1)     */
+#define DFL_DYN_BS 2       /* block (noise) rows this cycle                     */
+#define DFL_DYN_POS0 3     /* absolute position id of the first context row     */
+#define DFL_DYN_START 4    /* `start` of the decode loop (= pos0 + tau)         */
+#define DFL_DYN_STOP 5     /* 1 once a stop token was committed                 */
+#define DFL_DYN_CYCLE 6    /* cycles run                                        */
+
+int dfl_version(void);
+const char *dfl_last_error(void);
+
+/* ---- one-time layout conversion (weight load; not on the per-cycle path) ---- */
+
+/* nn.Linear weight [N][K] bf16 row-major -> packed weight.  N%16==0, K%32==0. */
+int dfl_pack_weight(const void *w, void *wp, int N, int K, void *stream);
+/* gate_proj and up_proj [I][K] each -> one packed weight of 2I rows with tiles
+ * interleaved (gate tile t, up tile t) so SiLU(gate)*up fuses into the GEMM
+ * epilogue (tf:models/qwen3/modeling_qwen3.py:81-83). */
+int dfl_pack_weight_gateup(const void *gate, const void *up, void *wp, int I, int K, void *stream);
+
+/* ---- per-cycle kernels ---- */
+
+/* dyn <- {S, tau, bs, pos0, start=pos0+tau, stop=0, cycle=0}. */
+int dfl_set_dyn(int32_t *dyn, int S, int tau, int bs, int pos0, void *stream);
+
+/* rows x K bf16 (row stride ldx elements) -> frag16; rows beyond n_valid zeroed.
+ * n_valid = dyn[dyn_word] if dyn != NULL else rows.  Used for the target taps
+ * (model/utils.py:16-25 output) feeding fc. */
+int dfl_pack_rows(const void *x, int64_t ldx, int rows, int K, void *xf, const int32_t *dyn, int dyn_word,
+                  void *stream);
+
+/* Skinny GEMM, weights streamed once: out[c][mt*16+m][n] = sum_{k in chunk c} x_mt[m][k] * W[n][k]
+ * (fp32 partials, summed and rounded to bf16 by the consumer exactly where the
+ * reference's nn.Linear output is rounded).  Replaces F.linear at model/dflash.py:70,
+ * 73-76,101,177 and the down_proj of tf:...modeling_qwen3.py:82.
+ * mt in {1,2} row tiles (xf1 ignored for mt==1), N%16==0, K%32==0,
+ * out has ksplit*mt*16*N floats; ksplit >= ceil(K/32 / (16*8/mt)). */
+int dfl_gemm_f32(const void *wp, const void *xf0, const void *xf1, int mt, int N, int K, int ksplit, float *out,
+                 void *stream);
+
+/* act = bf16(silu(bf16(x Wg^T))) * bf16(x Wu^T) written as frag16 [I/8][16][8]
+ * (tf:...modeling_qwen3.py:82 inner expression).  wp from dfl_pack_weight_gateup.
+ * K/32 <= 128 (no K split: the activation needs the finished sums). */
+int dfl_gemm_silu_mul(const void *wp_gateup, const void *xf, int I, int K, void *act_frag, void *stream);
+
+/* lm_head GEMM fused with the greedy unmask: ids[r] = argmax_n bf16(x[r] . W[n])
+ * for r in [row0, row0+nrows), first index on ties (model/dflash.py:238-247 +
+ * model/utils.py:28-29).  The 15 x V logits are never materialised unless
+ * `logits` != NULL (bf16 [16][V], rows outside the range untouched).
+ * ws: workspace of dfl_argmax_ws_bytes() bytes.  out_ids int64, written at
+ * out_ids[r - row0 + out_off]. nrows_dyn_word >= 0: rows = dyn[word] - row0. */
+int64_t dfl_argmax_ws_bytes(void);
+int dfl_gemm_argmax(const void *wp, const void *xf, int V, int K, int row0, int nrows, const int32_t *dyn,
+                    int nrows_dyn_word, void *ws, int64_t *out_ids, int out_off, void *logits, void *stream);
+
+/* Row-wise residual/norm stage that also converts to frag16:
+ *   v   = part ? bf16(sum_c part[c][row_off+m][:]) : (none)
+ *   h   = embed ? embed[ids[m]] : resid_in ? resid_in[m] : 0       (bf16)
+ *   h   = part ? (resid_in||embed ? bf16(h + v) : v) : h            (model/dflash.py:140,144)
+ *   h_out[m] = h                                   (if h_out)
+ *   frag[m]  = norm_w * bf16(h * rsqrt(mean(h^2)+eps))  (Qwen3RMSNorm, tf:...:59-64)
+ * rows m >= n_valid (dyn[dyn_word], or 16) get zero fragments.  H%8==0, H<=16384.
+ * part row stride ldp floats, split stride part_split floats. */
+int dfl_norm_pack(const float *part, int nsplit, int64_t part_split, int ldp, int row_off, const void *resid_in,
+                  const void *embed, const int64_t *ids, void *h_out, const void *norm_w, float eps, void *frag,
+                  int H, const int32_t *dyn, int dyn_word, void *stream);
+
+/* q_norm/k_norm + RoPE + KV append (model/dflash.py:71-85 with the local
+ * apply_rotary_pos_emb of :22-28).  qkv: fp32 partials from dfl_gemm_f32,
+ * element (split c, buffer row r, column j) at qkv[c*split_stride + r*ld + j];
+ * q/k/v column blocks start at q_col/k_col/v_col (q_col < 0: no q wanted);
+ * context rows sit at buffer rows ctx_row0.., block rows at blk_row0.. (< 0: none).
+ * Writes
+ *   q_out  bf16 [n_q][16][128]       (block rows only: q uses the last bs positions)
+ *   kcache/vcache bf16 [n_kv][cache_rows][128] at rows S + rel, rel = row_base + i
+ *   for context row i, tau + j for block row j; RoPE position = pos0 + rel.
+ * cos/sin: bf16 [max_pos][64] tables (tf:...:125-137, computed by the host in fp32
+ * then cast, as the reference does).  head_dim must be 128.
+ * ctx_rows_override >= 0: that many context rows instead of dyn tau and no block
+ * rows — the draft-cache prefill of the prompt's context in 16-row groups, with
+ * row_base = index of the group's first row. */
+int dfl_qknorm_rope_append(const float *qkv, int nsplit, int64_t split_stride, int ld, int q_col, int k_col,
+                           int v_col, int ctx_row0, int blk_row0, int n_q, int n_kv, const void *q_norm_w,
+                           const void *k_norm_w, float eps, const void *cos_tab, const void *sin_tab, int max_pos,
+                           void *q_out, void *kcache, void *vcache, int cache_rows, const int32_t *dyn,
+                           int ctx_rows_override, int row_base, void *stream);
+
+/* Bidirectional (mask-free, is_causal=False) GQA attention of the block's 16 query
+ * rows over the cached prefix + this cycle's rows: softmax(q k^T * scale) v over
+ * kv_len = S + tau + bs keys (model/dflash.py:86-99).  MFMA QK^T / PV, K/V tiles
+ * staged in LDS, split over the key axis with a log-sum-exp merge.
+ * ws: dfl_attn_ws_bytes(n_q, max_splits) bytes.  out: frag16 [n_q*128/8][16][8]. */
+int64_t dfl_attn_ws_bytes(int n_q, int max_splits);
+int dfl_block_attn(const void *q, const void *kcache, const void *vcache, int cache_rows, int n_q, int n_kv,
+                   float scale, const int32_t *dyn, int kv_len_max, void *ws, int max_splits, void *out_frag,
+                   void *stream);
+
+/* First-max-index argmax over the last axis (model/utils.py:28-29).
+ * dtype: 0 = bf16, 1 = fp32.  ids int64 [rows]. */
+int dfl_argmax(const void *logits, int dtype, int rows, int64_t V, int64_t *ids, void *stream);
+
+/* Acceptance scan + commit + bonus token + stop test + length bookkeeping in one
+ * wavefront (model/dflash.py:258-268):
+ *   acc = #leading i with block[i+1] == posterior[i]           (0..bs-1)
+ *   output_ids[start .. start+acc] = block[0..acc]; output_ids[start+acc+1] = posterior[acc]
+ *   dyn: S <- start, tau <- acc+1, pos0 <- start, start <- start+acc+1, cycle++, stop |= any stop id
+ *        among the acc+2 tokens just written
+ * result (int32[4], may be pinned host memory mapped to the device): {acc, new_start, stop, cycle}. */
+int dfl_accept_commit(const int64_t *block_ids, const int64_t *posterior, int bs, int64_t *output_ids,
+                      int64_t output_len, int32_t *dyn, const int64_t *stop_ids, int n_stop, int32_t *result,
+                      void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFLASH_HIP_H */

@@ -1,0 +1,316 @@
+"""GPU parity of each C-ABI kernel against the oracle's leaf ops / plain fp32 torch
+math on the same seeded inputs.  Integer-valued inputs give exact (layout) checks;
+random bf16 inputs are checked within a stated tolerance."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+BF16 = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    from dflash_amd import ops as o
+    return o
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+def gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def unfrag(frag, K):
+    return frag.view(K // 8, 16, 8).permute(1, 0, 2).reshape(16, K)
+
+
+def to_frag(ops, x):  # x [rows<=16, K] bf16 cuda
+    out = torch.empty(16 * x.shape[1], dtype=BF16, device=x.device)
+    ops.pack_rows(x, x.shape[0], out)
+    return out
+
+
+# ------------------------------------------------------------------ layout
+def test_pack_rows_roundtrip(ops):
+    x = torch.randn(11, 512, generator=gen(0)).to(BF16).to(dev())
+    fr = to_frag(ops, x)
+    back = unfrag(fr, 512)
+    assert torch.equal(back[:11], x)
+    assert torch.count_nonzero(back[11:]) == 0
+
+
+@pytest.mark.parametrize("N,K,rows,ksplit", [(64, 512, 16, 1), (48, 1024, 5, 1), (4096, 4096, 16, 1),
+                                            (256, 4096 * 3, 16, 3), (512, 2560, 16, 1), (128, 9728, 7, 3),
+                                            (64, 512, 16, 2)])
+def test_gemm_f32_exact_small_ints(ops, N, K, rows, ksplit):
+    """Small-integer operands: every product and partial sum is exact in fp32, so the
+    result must equal torch's bit for bit — a pure test of fragment layouts, K
+    splitting and the LDS reduction.  Asymmetric operands (guide §3)."""
+    g = gen(N + K)
+    w = torch.randint(-3, 4, (N, K), generator=g).to(BF16).to(dev())
+    x = torch.randint(-2, 3, (rows, K), generator=g).to(BF16).to(dev())
+    wp = ops.pack_weight(w)
+    xf = to_frag(ops, x)
+    out = torch.full((ksplit, 16, N), float("nan"), device=dev())
+    ops.gemm_f32(wp, xf, None, 1, N, K, ksplit, out)
+    got = out.sum(0)[:rows]
+    ref = x.float() @ w.float().t()
+    assert torch.equal(got, ref)
+
+
+def test_gemm_f32_two_row_tiles(ops):
+    N, K = 6144, 4096
+    g = gen(5)
+    w = (torch.randn(N, K, generator=g) * 0.02).to(BF16).to(dev())
+    x0 = torch.randn(7, K, generator=g).to(BF16).to(dev())
+    x1 = torch.randn(16, K, generator=g).to(BF16).to(dev())
+    wp = ops.pack_weight(w)
+    ks = ops.min_ksplit(K, 2)
+    out = torch.zeros(ks, 32, N, device=dev())
+    ops.gemm_f32(wp, to_frag(ops, x0), to_frag(ops, x1), 2, N, K, ks, out)
+    got = out.sum(0)
+    ref0, ref1 = x0.float() @ w.float().t(), x1.float() @ w.float().t()
+    # fp32 accumulation in a different order than torch: relative 1e-4 of the row scale
+    for a, b in ((got[:7], ref0), (got[16:], ref1)):
+        assert (a - b).abs().max() <= 2e-4 * b.abs().max()
+
+
+def test_gemm_silu_mul(ops):
+    I, K = 2560, 1024
+    g = gen(6)
+    wg = (torch.randn(I, K, generator=g) * 0.05).to(BF16).to(dev())
+    wu = (torch.randn(I, K, generator=g) * 0.05).to(BF16).to(dev())
+    x = torch.randn(16, K, generator=g).to(BF16).to(dev())
+    act = torch.empty(16 * I, dtype=BF16, device=dev())
+    ops.gemm_silu_mul(ops.pack_weight_gateup(wg, wu), to_frag(ops, x), I, K, act)
+    got = unfrag(act, I).float()
+    gl = (x.float() @ wg.float().t()).to(BF16)
+    ul = (x.float() @ wu.float().t()).to(BF16)
+    ref = (torch.nn.functional.silu(gl.float()).to(BF16).float() * ul.float()).to(BF16).float()
+    # identical rounding points; residual differences are 1-ulp flips of the two bf16 Linear outputs
+    assert (got - ref).abs().max() <= 2 ** -6 * ref.abs().max()
+    assert ((got - ref).abs() > 0).float().mean() < 0.05
+
+
+def test_gemm_silu_mul_exact_ints(ops):
+    I, K = 64, 512
+    g = gen(7)
+    wg = torch.randint(-1, 2, (I, K), generator=g).to(BF16).to(dev())
+    wu = torch.randint(-1, 2, (I, K), generator=g).to(BF16).to(dev())
+    x = torch.zeros(16, K, dtype=BF16)
+    x[:, :8] = torch.randint(-1, 2, (16, 8), generator=g).to(BF16)
+    x = x.to(dev())
+    act = torch.empty(16 * I, dtype=BF16, device=dev())
+    ops.gemm_silu_mul(ops.pack_weight_gateup(wg, wu), to_frag(ops, x), I, K, act)
+    gl, ul = x.float() @ wg.float().t(), x.float() @ wu.float().t()
+    ref = (torch.nn.functional.silu(gl).to(BF16).float() * ul).to(BF16).float()
+    got = unfrag(act, I).float()
+    assert (got - ref).abs().max() <= 2 ** -7 * max(1.0, ref.abs().max())  # __expf vs torch exp
+
+
+@pytest.mark.parametrize("V,K,bs", [(2048, 512, 16), (4096 + 16 * 7, 1024, 12), (151936, 4096, 16)])
+def test_gemm_argmax(ops, V, K, bs):
+    g = gen(V)
+    w = (torch.randn(V, K, generator=g) * 0.02).to(BF16).to(dev())
+    x = torch.randn(16, K, generator=g).to(BF16).to(dev())
+    w[V // 3] = w[5]          # duplicated rows: exact ties, the lower index must win
+    w[V - 1] = w[5]
+    wp = ops.pack_weight(w)
+    ids = torch.full((16,), -1, dtype=torch.long, device=dev())
+    logits = torch.zeros(16, V, dtype=BF16, device=dev())
+    ops.gemm_argmax(wp, to_frag(ops, x), V, K, 1, bs - 1, ops.argmax_ws(dev()), ids, 1, logits=logits)
+    ref_logits = (x.float() @ w.float().t())
+    assert (logits[1:bs].float() - ref_logits[1:bs]).abs().max() <= 2 ** -7 * ref_logits.abs().max()
+    # ids are the first-max index of the kernel's own bf16 logits (the reference's argmax semantics)
+    assert torch.equal(ids[1:bs], torch.argmax(logits[1:bs], dim=-1))
+    assert int(ids[0]) == -1 and (ids[bs:] == -1).all()
+    # and, with the fused path (no logits written), the same ids
+    ids2 = torch.full((16,), -1, dtype=torch.long, device=dev())
+    ops.gemm_argmax(wp, to_frag(ops, x), V, K, 1, bs - 1, ops.argmax_ws(dev()), ids2, 1)
+    assert torch.equal(ids, ids2)
+
+
+def test_gemm_argmax_forced_tie(ops):
+    V, K = 2048, 512
+    w = torch.zeros(V, K, dtype=BF16)
+    w[[77, 900, 2047], 0] = 1.0
+    x = torch.zeros(16, K, dtype=BF16)
+    x[:, 0] = 1.0
+    ids = torch.zeros(16, dtype=torch.long, device=dev())
+    ops.gemm_argmax(ops.pack_weight(w.to(dev())), to_frag(ops, x.to(dev())), V, K, 0, 16, ops.argmax_ws(dev()), ids, 0)
+    assert (ids == 77).all()
+    x[:, 0] = -1.0   # now all maxima are the zero rows: index 0 wins
+    ops.gemm_argmax(ops.pack_weight(w.to(dev())), to_frag(ops, x.to(dev())), V, K, 0, 16, ops.argmax_ws(dev()), ids, 0)
+    assert (ids == 0).all()
+
+
+# ------------------------------------------------------------------ row stages
+def test_norm_pack_variants(ops):
+    from oracle.dflash_oracle import rms_norm
+    Hd = 1024
+    g = gen(8)
+    nw = (1 + 0.1 * torch.randn(Hd, generator=g)).to(BF16)
+    part = torch.randn(3, 16, Hd, generator=g)
+    resid = torch.randn(16, Hd, generator=g).to(BF16)
+    dyn = torch.zeros(8, dtype=torch.int32, device=dev())
+    ops.set_dyn(dyn, 0, 5, 12, 0)
+    frag = torch.empty(16 * Hd, dtype=BF16, device=dev())
+    hout = torch.zeros(16, Hd, dtype=BF16, device=dev())
+    # partial sums + residual (o_proj / down_proj epilogue), 12 valid rows
+    ops.norm_pack(norm_w=nw.to(dev()), frag=frag, H=Hd, eps=1e-6, part=part.to(dev()), nsplit=3,
+                  part_split=16 * Hd, ldp=Hd, resid_in=resid.to(dev()), h_out=hout, dyn=dyn, dyn_word=ops.DYN_BS)
+    h_ref = resid + part.sum(0).to(BF16)
+    n_ref = rms_norm(h_ref, nw, 1e-6)
+    assert torch.equal(hout[:12].cpu(), h_ref[:12])
+    got = unfrag(frag, Hd).cpu()
+    assert torch.count_nonzero(got[12:]) == 0
+    d = (got[:12].float() - n_ref[:12].float()).abs()
+    assert d.max() <= 2 ** -6 * n_ref.float().abs().max() and (d > 0).float().mean() < 0.02
+    # partial only (fc -> hidden_norm), 5 valid rows
+    ops.norm_pack(norm_w=nw.to(dev()), frag=frag, H=Hd, eps=1e-6, part=part.to(dev()), nsplit=3,
+                  part_split=16 * Hd, ldp=Hd, dyn=dyn, dyn_word=ops.DYN_TAU)
+    n_ref = rms_norm(part.sum(0).to(BF16), nw, 1e-6)
+    got = unfrag(frag, Hd).cpu()
+    assert torch.count_nonzero(got[5:]) == 0
+    assert (got[:5].float() - n_ref[:5].float()).abs().max() <= 2 ** -6 * n_ref.float().abs().max()
+    # embedding gather
+    emb = torch.randn(100, Hd, generator=g).to(BF16)
+    ids = torch.randint(0, 100, (16,), generator=g)
+    ops.norm_pack(norm_w=nw.to(dev()), frag=frag, H=Hd, eps=1e-6, embed=emb.to(dev()), ids=ids.to(dev()),
+                  h_out=hout, dyn=dyn, dyn_word=ops.DYN_BS)
+    assert torch.equal(hout[:12].cpu(), emb[ids][:12])
+    n_ref = rms_norm(emb[ids], nw, 1e-6)
+    assert (unfrag(frag, Hd).cpu()[:12].float() - n_ref[:12].float()).abs().max() <= 2 ** -6 * n_ref.float().abs().max()
+
+
+def test_qknorm_rope_append(ops):
+    from oracle import dflash_oracle as O
+    from dflash_amd.model import _rope_tables
+    n_q, n_kv, S, tau, bs = 8, 2, 37, 5, 12
+    ld = (n_q + 2 * n_kv) * 128
+    g = gen(9)
+    part = torch.randn(2, 32, ld, generator=g)
+    qw = (1 + 0.1 * torch.randn(128, generator=g)).to(BF16)
+    kw = (1 + 0.1 * torch.randn(128, generator=g)).to(BF16)
+    cos, sin = _rope_tables(128, 1e6, 256, dev())
+    dyn = torch.zeros(8, dtype=torch.int32, device=dev())
+    ops.set_dyn(dyn, S, tau, bs, S)
+    kc = torch.zeros(n_kv, 128, 128, dtype=BF16, device=dev())
+    vc = torch.zeros_like(kc)
+    q_out = torch.zeros(n_q, 16, 128, dtype=BF16, device=dev())
+    ops.qknorm_rope_append(qkv=part.to(dev()), nsplit=2, split_stride=32 * ld, ld=ld, q_col=0, k_col=n_q * 128,
+                           v_col=(n_q + n_kv) * 128, ctx_row0=0, blk_row0=16, n_q=n_q, n_kv=n_kv,
+                           q_norm_w=qw.to(dev()), k_norm_w=kw.to(dev()), eps=1e-6, cos_tab=cos, sin_tab=sin,
+                           q_out=q_out, kcache=kc, vcache=vc, dyn=dyn)
+    lin = part.sum(0).to(BF16)                      # the Linear outputs
+    rows = torch.cat([lin[:tau], lin[16:16 + bs]])  # [tau+bs, ld]
+    q = lin[16:16 + bs, :n_q * 128].view(1, bs, n_q, 128)
+    k = rows[:, n_q * 128:(n_q + n_kv) * 128].view(1, tau + bs, n_kv, 128)
+    v = rows[:, (n_q + n_kv) * 128:].view(1, tau + bs, n_kv, 128).transpose(1, 2)
+    q = O.rms_norm(q, qw, 1e-6).transpose(1, 2)
+    k = O.rms_norm(k, kw, 1e-6).transpose(1, 2)
+    pos = torch.arange(S, S + tau + bs)[None]
+    c, s = O.rope_cos_sin(pos, O.rope_inv_freq(128, 1e6), BF16)
+    q, k = O.apply_rotary_dflash(q, k, c, s)
+    assert torch.equal(vc[:, S:S + tau + bs].cpu(), v[0])
+    assert torch.count_nonzero(vc[:, :S]) == 0 and torch.count_nonzero(vc[:, S + tau + bs:]) == 0
+    for got, ref in ((kc[:, S:S + tau + bs].cpu(), k[0]), (q_out[:, :bs].cpu(), q[0])):
+        d = (got.float() - ref.float()).abs()
+        assert d.max() <= 2 ** -6 * ref.float().abs().max() and (d > 0).float().mean() < 0.02
+
+
+@pytest.mark.parametrize("n_q,n_kv,S,tau,bs", [(4, 2, 0, 3, 16), (8, 2, 100, 16, 16), (32, 8, 1024, 7, 16),
+                                               (32, 4, 517, 1, 8), (8, 8, 31, 1, 12), (32, 8, 4000, 16, 16)])
+def test_block_attn(ops, n_q, n_kv, S, tau, bs):
+    g = gen(S + n_q)
+    kv_len = S + tau + bs
+    rows = kv_len + 40
+    q = torch.randn(n_q, 16, 128, generator=g).to(BF16)
+    k = torch.randn(n_kv, rows, 128, generator=g).to(BF16)
+    v = torch.randn(n_kv, rows, 128, generator=g).to(BF16)
+    k[0, 3] *= 4.0  # a spike, so one tile's max dominates and the rescale path matters
+    dyn = torch.zeros(8, dtype=torch.int32, device=dev())
+    ops.set_dyn(dyn, S, tau, bs, S)
+    out = torch.empty(16 * n_q * 128, dtype=BF16, device=dev())
+    ms = 32
+    ops.block_attn(q=q.to(dev()), kcache=k.to(dev()), vcache=v.to(dev()), n_q=n_q, n_kv=n_kv, scale=128 ** -0.5,
+                   dyn=dyn, kv_len_max=kv_len, ws=ops.attn_ws(n_q, ms, dev()), max_splits=ms, out_frag=out)
+    got = unfrag(out, n_q * 128).cpu().float().view(16, n_q, 128)
+    G = n_q // n_kv
+    kk = k[:, :kv_len].float().repeat_interleave(G, dim=0)
+    vv = v[:, :kv_len].float().repeat_interleave(G, dim=0)
+    p = torch.softmax(torch.einsum("hqd,hkd->hqk", q.float(), kk) * 128 ** -0.5, dim=-1)
+    ref = torch.einsum("hqk,hkd->qhd", p, vv)
+    # bf16 P and bf16 output: 2^-7 relative of the output scale
+    assert (got - ref).abs().max() <= 2 ** -6 * ref.abs().max()
+    assert torch.isfinite(got).all()
+
+
+# ------------------------------------------------------------------ integer side, golden
+def test_argmax_golden(ops):
+    z = np.load(os.path.join(H.GOLDEN, "argmax.npz"))
+    lb = torch.from_numpy(z["logits_bf16"]).to(BF16).to(dev())
+    assert np.array_equal(ops.argmax(lb).cpu().numpy(), z["ids_bf16"])
+    lf = torch.from_numpy(z["logits_f32"]).to(dev())
+    assert np.array_equal(ops.argmax(lf).cpu().numpy(), z["ids_f32"])
+    big = torch.randn(3, 151936, generator=gen(1)).to(BF16).to(dev())
+    assert torch.equal(ops.argmax(big), torch.argmax(big, dim=-1))
+
+
+def test_accept_commit_golden(ops):
+    for c in json.load(open(os.path.join(H.GOLDEN, "accept.json"))):
+        out = torch.full((len(c["out"]),), 9999, dtype=torch.long, device=dev())
+        dyn = torch.zeros(8, dtype=torch.int32, device=dev())
+        res = torch.zeros(4, dtype=torch.int32, device=dev())
+        ops.set_dyn(dyn, 0, 0, c["bs"], c["start"])
+        ops.accept_commit(torch.tensor(c["block"], device=dev()), torch.tensor(c["posterior"], device=dev()),
+                          c["bs"], out, dyn, None, res)
+        assert res.tolist()[:3] == [c["acc"], c["new_start"], 0]
+        assert out.tolist() == c["out"]
+        d = dyn.tolist()
+        assert (d[0], d[1], d[3], d[4]) == (c["start"], c["acc"] + 1, c["start"], c["new_start"])
+
+
+def test_accept_commit_stop_flag(ops):
+    block = torch.tensor([5, 6, 7, 8], device=dev())
+    post = torch.tensor([6, 7, 99, 3], device=dev())   # acc = 2, bonus token 99
+    for stops, want in (([99], 1), ([8], 0), ([7, 1000], 1), ([3], 0)):
+        out = torch.zeros(20, dtype=torch.long, device=dev())
+        dyn = torch.zeros(8, dtype=torch.int32, device=dev())
+        res = torch.zeros(4, dtype=torch.int32, device=dev())
+        ops.set_dyn(dyn, 0, 0, 4, 10)
+        ops.accept_commit(block, post, 4, out, dyn, torch.tensor(stops, device=dev()), res)
+        assert res.tolist()[:3] == [2, 13, want], stops
+        assert out.tolist()[10:14] == [5, 6, 7, 99]
+
+
+def test_sample_temperature_posterior(ops):
+    """T>0 (BASELINE config 4): the posterior draw stays torch.multinomial; given the
+    reference's sampled ids the acceptance kernel reproduces its length."""
+    z = np.load(os.path.join(H.GOLDEN, "sample_t.npz"))
+    out = torch.zeros(64, dtype=torch.long, device=dev())
+    dyn = torch.zeros(8, dtype=torch.int32, device=dev())
+    res = torch.zeros(4, dtype=torch.int32, device=dev())
+    ops.set_dyn(dyn, 0, 0, 16, 3)
+    ops.accept_commit(torch.from_numpy(z["block"][0]).to(dev()), torch.from_numpy(z["ids"][0]).to(dev()), 16, out,
+                      dyn, None, res)
+    assert res.tolist()[0] == int(z["acc"])
+
+
+def test_rejects_bad_arguments(ops):
+    from dflash_amd._lib import DFlashHipError
+    w = torch.zeros(20, 512, dtype=BF16, device=dev())
+    with pytest.raises(DFlashHipError):
+        ops.pack_weight(w)                       # N % 16 != 0
+    with pytest.raises(RuntimeError):
+        ops.argmax(torch.zeros(2, 8))            # CPU tensor: no host path
