@@ -39,9 +39,15 @@ void dfl_set_error(const char *fmt, ...);
 // ---- device helpers ---------------------------------------------------------
 // Round-to-nearest-even fp32 -> bf16 via the hardware convert (keeps NaN a NaN).
 __device__ __forceinline__ bf16_t f2bf(float x) { return (bf16_t)x; }
-__device__ __forceinline__ float bf2f(bf16_t x) { return (float)x; }
+// bf16 -> fp32 through the bit pattern.  NOT `(float)b`: clang evaluates __bf16
+// expressions with excess precision by default, and a float->bf16->float cast pair
+// in the middle of an expression is then folded away (measured: the RoPE products
+// came out unrounded).  The integer shift is opaque to that folding.
+__device__ __forceinline__ float bf2f(bf16_t x) {
+  return __builtin_bit_cast(float, (uint32_t)__builtin_bit_cast(unsigned short, x) << 16);
+}
 // value after one bf16 rounding, kept in fp32 (where torch would have stored bf16)
-__device__ __forceinline__ float rbf(float x) { return (float)((bf16_t)x); }
+__device__ __forceinline__ float rbf(float x) { return bf2f((bf16_t)x); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
