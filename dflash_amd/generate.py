@@ -7,7 +7,8 @@ return fields:
                              `EWMAPerformanceScheduler` every cycle)
 * `DFlashDraftModel.spec_generate` (model.py) — model/dflash.py:192-277
 
-All three share `run_decode`.  Per cycle the host enqueues: draft forward + fused
+All three drive a `DecodeSession` (prefill once, then `cycle()` per block), which
+bench.py also steps directly.  Per cycle the host enqueues: draft forward + fused
 lm_head/argmax (kernels), the caller's target forward (PyTorch-ROCm, outside the
 path), the posterior argmax kernel and the accept/commit kernel; the only
 device->host read is the 4-int accept result the loop needs to slice the
@@ -17,12 +18,14 @@ from __future__ import annotations
 
 import time
 from types import SimpleNamespace
-from typing import Callable, Optional, Sequence
+from typing import Callable, Optional
 
 import torch
 
 from . import ops
 from .utils import extract_context_feature, sample
+
+_TABLES = {}
 
 
 def cuda_time() -> float:
@@ -35,178 +38,6 @@ def _new_target_cache(target):
         return target.new_cache()
     from transformers import DynamicCache  # the reference's choice (model/dflash.py:214)
     return DynamicCache()
-
-
-def _trim(output_ids, max_length, mask_token_id, stop_token_ids, n_in):
-    """model/dflash.py:269-275."""
-    output_ids = output_ids[:, :max_length]
-    output_ids = output_ids[:, output_ids[0] != mask_token_id]
-    if stop_token_ids is not None:
-        st = torch.tensor(stop_token_ids, device=output_ids.device)
-        idx = torch.isin(output_ids[0][n_in:], st).nonzero(as_tuple=True)[0]
-        if idx.numel() > 0:
-            output_ids = output_ids[:, : n_in + idx[0] + 1]
-    return output_ids
-
-
-@torch.inference_mode()
-def run_decode(model, target, input_ids: torch.Tensor, *, mask_token_id: int, max_new_tokens: int,
-               block_size: int, stop_token_ids, temperature: float, clamp_tail: bool,
-               draft_steps: int = 1, collect_profile: bool = False, scheduler=None,
-               draft_temperature: float = 0.0, draft_token_hook: Optional[Callable] = None,
-               max_block_size: Optional[int] = None) -> SimpleNamespace:
-    dev = model.device
-    if not input_ids.is_cuda:
-        raise RuntimeError("dflash_amd: input_ids must be on the GPU")
-    if input_ids.shape[0] != 1:
-        raise NotImplementedError("batch = 1 per call, as in the reference; shard requests over ranks/streams")
-    max_bs = max_block_size or block_size
-    n_in = input_ids.shape[1]
-    max_length = n_in + max_new_tokens
-    output_ids = torch.full((1, max_length + max_bs), mask_token_id, dtype=torch.long, device=dev)
-    position_ids = torch.arange(output_ids.shape[1], device=dev).unsqueeze(0)
-    tcache = _new_target_cache(target)
-    use_draft = max_bs > 1
-    dcache = model.new_cache(max_length + 2 * max_bs) if use_draft else None
-    embed_w = _bf16_table(target.model.embed_tokens.weight, dev)
-    lm_wp = model.packed_lm_head(target.lm_head) if use_draft else None
-    stop_t = torch.tensor(stop_token_ids, dtype=torch.long, device=dev) if stop_token_ids else None
-    stop_always = stop_token_ids is not None and mask_token_id in stop_token_ids  # reference scans mask slots too
-    result = torch.zeros(4, dtype=torch.int32, device=dev)
-    block = torch.empty(1, max_bs, dtype=torch.long, device=dev)
-
-    # ---- prefill (model/dflash.py:218-229)
-    t_prefill = cuda_time()
-    out = target(input_ids, position_ids=position_ids[:, :n_in], past_key_values=tcache, use_cache=True,
-                 logits_to_keep=1, output_hidden_states=use_draft)
-    output_ids[:, :n_in] = input_ids
-    output_ids[:, n_in:n_in + 1] = sample(out.logits, temperature)
-    target_hidden = _taps(out.hidden_states, model.target_layer_ids) if use_draft else None
-    time_to_first_token = cuda_time() - t_prefill
-
-    decode_start = cuda_time()
-    start = n_in
-    taus, used_bs, cycle_trace, lgens = [], [], [], []
-    draft_prefill = True
-    hook_calls = 0
-    cyc = 0
-    while start < max_length:
-        cycle_t0 = cuda_time() if scheduler is not None else None
-        ev = None
-        if collect_profile:
-            ev = {k: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                  for k in ("cycle", "draft", "target")}
-            ev["cycle"][0].record()
-        chosen = block_size if scheduler is None else scheduler.select(cyc)
-        remaining = max_length - start
-        bs = max(1, min(chosen, remaining)) if (clamp_tail or scheduler is not None) else chosen
-        l_gen = float(bs)
-        blk = block[:, :bs]
-        blk.copy_(output_ids[:, start:start + bs])
-        if bs > 1:
-            if collect_profile:
-                ev["draft"][0].record()
-            if draft_steps == 1:
-                ctx = target_hidden[0]
-                S = dcache.get_seq_length()
-                if ctx.shape[0] > 16:  # cycle 0: the prompt's context rows, 16 at a time
-                    head = ctx.shape[0] - 16
-                    model.prefill_context(dcache, ctx[:head], S)
-                    ctx, S = ctx[head:], S + head
-                hid = model.draft_block(dcache, th_rows=ctx, tau=ctx.shape[0], bs=bs, pos0=S, block_ids=blk[0],
-                                        embed=embed_w)
-                _draft_ids(model, hid, lm_wp, bs, blk, draft_temperature)
-                if draft_token_hook is not None:
-                    draft_token_hook(blk, start, hook_calls)
-                hook_calls += 1
-            else:
-                # benchmark.py:112-142: k full passes, each re-embedding the whole block, no
-                # draft cache, positions rebuilt as [start-ctx_len, start+bs)
-                ctx = target_hidden[0]
-                ctx_len = ctx.shape[0]
-                for _ in range(draft_steps):
-                    tmp = model.new_cache(ctx_len + bs)
-                    p0 = max(0, start - ctx_len)
-                    c2 = ctx
-                    if ctx_len > 16:
-                        model.prefill_context(tmp, ctx[:ctx_len - 16], p0)
-                        c2, p0 = ctx[ctx_len - 16:], p0 + ctx_len - 16
-                    hid = model.draft_block(tmp, th_rows=c2, tau=c2.shape[0], bs=bs, pos0=p0, block_ids=blk[0],
-                                            embed=embed_w, append=False)
-                    _draft_ids(model, hid, lm_wp, bs, blk, 0.0)
-                    if draft_token_hook is not None:
-                        draft_token_hook(blk, start, hook_calls)
-                    hook_calls += 1
-            if scheduler is not None and stop_t is not None:
-                pos = torch.isin(blk[0, 1:], stop_t).nonzero(as_tuple=True)[0]
-                if pos.numel() > 0:
-                    l_gen = float(min(int(pos[0].item()) + 1, bs))
-            if collect_profile:
-                ev["draft"][1].record()
-            if draft_prefill:
-                draft_prefill = False
-                decode_start = cuda_time()
-
-        # ---- target verify (outside the path; model/dflash.py:249-255)
-        if collect_profile:
-            ev["target"][0].record()
-        want_hidden = use_draft if (scheduler is not None or not clamp_tail) else bs > 1
-        out = target(blk, position_ids=position_ids[:, start:start + bs], past_key_values=tcache, use_cache=True,
-                     output_hidden_states=want_hidden)
-        if collect_profile:
-            ev["target"][1].record()
-        posterior = sample(out.logits, temperature)
-
-        # ---- accept scan + commit + bookkeeping on the device (:258-268)
-        dyn = dcache.dyn if dcache is not None else _scratch_dyn(dev)
-        ops.set_dyn(dyn, 0, 0, bs, start)  # start word = pos0 + tau = start
-        ops.accept_commit(blk[0], posterior[0].contiguous(), bs, output_ids[0], dyn, stop_t, result)
-        res = result.tolist()  # the cycle's one device->host read (synchronises the stream)
-        acc = res[0]
-        tau = acc + 1
-        taus.append(tau)
-        used_bs.append(bs)
-        lgens.append(l_gen)
-        gen_before = start - n_in
-        if scheduler is not None:
-            cycle_s = cuda_time() - cycle_t0
-            scheduler.update(tau=tau, cycle_s=cycle_s, effective_bs=bs, cycle_idx=cyc, l_gen=l_gen)
-            cycle_trace.append({
-                "cycle_idx": cyc, "start_idx": int(start), "block_size": int(bs), "chosen_block_size": int(chosen),
-                "tau": int(tau), "l_gen": float(l_gen), "acceptance_ratio": float(tau / max(1, bs)),
-                "cycle_s": float(cycle_s), "tau_hat": scheduler.tau_hat.get(bs),
-                "cycle_hat": scheduler.cycle_hat.get(bs), "score_hat": scheduler.score_hat.get(bs),
-                "current_block_size": int(scheduler.current), "adl_lgen_hat": scheduler.adl_lgen_hat,
-                "adl_lacc_hat": scheduler.adl_lacc_hat, "adl_target_k": int(scheduler.adl_target_k),
-                "adl_target_bs": int(scheduler.adl_target_bs)})
-        elif collect_profile:
-            ev["cycle"][1].record()
-            cycle_trace.append({"cycle_idx": cyc, "generated_tokens_before": int(gen_before),
-                                "effective_block_size": int(bs), "tau": int(tau),
-                                "acceptance_ratio": float(tau / max(1, bs)), "_events": ev})
-        start += tau
-        tcache.crop(start)
-        if want_hidden and use_draft:
-            target_hidden = _taps(out.hidden_states, model.target_layer_ids)[:, :tau, :]
-        cyc += 1
-        if stop_always or res[2]:
-            break
-
-    output_ids = _trim(output_ids, max_length, mask_token_id, stop_token_ids, n_in)
-    num_output_tokens = output_ids.shape[1] - n_in
-    total_decode_time = cuda_time() - decode_start
-    profile_summary = None
-    if collect_profile and scheduler is None:
-        profile_summary = _resolve_profile(cycle_trace, time_to_first_token, total_decode_time)
-    return SimpleNamespace(output_ids=output_ids, num_input_tokens=n_in, num_output_tokens=num_output_tokens,
-                           time_to_first_token=time_to_first_token,
-                           time_per_output_token=total_decode_time / max(1, num_output_tokens),
-                           acceptance_lengths=taus, used_block_sizes=used_bs, l_gen=lgens,
-                           cycle_trace=cycle_trace, profile_summary=profile_summary)
-
-
-_DYN = {}
-_TABLES = {}
 
 
 def _taps(hidden_states, layer_ids):
@@ -226,10 +57,226 @@ def _bf16_table(w, dev):
     return _TABLES[key]
 
 
-def _scratch_dyn(dev):
-    if dev not in _DYN:
-        _DYN[dev] = torch.zeros(8, dtype=torch.int32, device=dev)
-    return _DYN[dev]
+def _trim(output_ids, max_length, mask_token_id, stop_token_ids, n_in):
+    """model/dflash.py:269-275."""
+    output_ids = output_ids[:, :max_length]
+    output_ids = output_ids[:, output_ids[0] != mask_token_id]
+    if stop_token_ids is not None:
+        st = torch.tensor(stop_token_ids, device=output_ids.device)
+        idx = torch.isin(output_ids[0][n_in:], st).nonzero(as_tuple=True)[0]
+        if idx.numel() > 0:
+            output_ids = output_ids[:, : n_in + idx[0] + 1]
+    return output_ids
+
+
+class DecodeSession:
+    """State of one request between cycles (what the reference keeps in local
+    variables of its while-loop, model/dflash.py:206-233)."""
+
+    def __init__(self, model, target, input_ids: torch.Tensor, *, mask_token_id: int, max_new_tokens: int,
+                 max_block_size: int, stop_token_ids, temperature: float, draft_temperature: float = 0.0,
+                 draft_token_hook: Optional[Callable] = None):
+        dev = model.device
+        if not input_ids.is_cuda:
+            raise RuntimeError("dflash_amd: input_ids must be on the GPU")
+        if input_ids.shape[0] != 1:
+            raise NotImplementedError("batch = 1 per call, as in the reference; shard requests over ranks")
+        self.model, self.target, self.dev = model, target, dev
+        self.input_ids = input_ids
+        self.mask_token_id, self.temperature = mask_token_id, temperature
+        self.draft_temperature, self.hook = draft_temperature, draft_token_hook
+        self.stop_token_ids = stop_token_ids
+        self.max_bs = max_block_size
+        self.n_in = input_ids.shape[1]
+        self.max_length = self.n_in + max_new_tokens
+        self.output_ids = torch.full((1, self.max_length + self.max_bs), mask_token_id, dtype=torch.long, device=dev)
+        self.position_ids = torch.arange(self.output_ids.shape[1], device=dev).unsqueeze(0)
+        self.tcache = _new_target_cache(target)
+        self.use_draft = self.max_bs > 1
+        self.dcache = model.new_cache(self.max_length + 2 * self.max_bs) if self.use_draft else None
+        self.dyn = self.dcache.dyn if self.dcache is not None else torch.zeros(8, dtype=torch.int32, device=dev)
+        self.embed_w = _bf16_table(target.model.embed_tokens.weight, dev)
+        self.lm_wp = model.packed_lm_head(target.lm_head) if self.use_draft else None
+        self.stop_t = torch.tensor(stop_token_ids, dtype=torch.long, device=dev) if stop_token_ids else None
+        # the reference scans the whole buffer, mask slots included (model/dflash.py:265-268)
+        self.stop_always = stop_token_ids is not None and mask_token_id in stop_token_ids
+        self.result = torch.zeros(4, dtype=torch.int32, device=dev)
+        self.block = torch.empty(1, self.max_bs, dtype=torch.long, device=dev)
+        self.start = self.n_in
+        self.target_hidden = None
+        self.hook_calls = 0
+        self.stopped = False
+        self.events = None  # set to a dict to have cycle() record (start, end) event pairs per phase
+
+    @torch.inference_mode()
+    def prefill(self) -> None:
+        """model/dflash.py:218-229."""
+        out = self.target(self.input_ids, position_ids=self.position_ids[:, :self.n_in],
+                          past_key_values=self.tcache, use_cache=True, logits_to_keep=1,
+                          output_hidden_states=self.use_draft)
+        self.output_ids[:, :self.n_in] = self.input_ids
+        self.output_ids[:, self.n_in:self.n_in + 1] = sample(out.logits, self.temperature)
+        if self.use_draft:
+            self.target_hidden = _taps(out.hidden_states, self.model.target_layer_ids)
+
+    def _mark(self, key, which):
+        if self.events is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.events.setdefault(key, [None, None])[which] = e
+
+    def _draft(self, blk, bs, draft_steps):
+        m = self.model
+        ctx = self.target_hidden[0]
+        if draft_steps == 1:
+            S = self.dcache.get_seq_length()
+            if ctx.shape[0] > 16:  # cycle 0: the prompt's context rows, 16 at a time
+                head = ctx.shape[0] - 16
+                m.prefill_context(self.dcache, ctx[:head], S)
+                ctx, S = ctx[head:], S + head
+            hid = m.draft_block(self.dcache, th_rows=ctx, tau=ctx.shape[0], bs=bs, pos0=S, block_ids=blk[0],
+                                embed=self.embed_w)
+            self._mark("lm_head", 0)
+            _draft_ids(m, hid, self.lm_wp, bs, blk, self.draft_temperature)
+            self._mark("lm_head", 1)
+            if self.hook is not None:
+                self.hook(blk, self.start, self.hook_calls)
+            self.hook_calls += 1
+            return
+        # benchmark.py:112-142: k full passes, each re-embedding the whole block, no draft
+        # cache, positions rebuilt as [start-ctx_len, start+bs)
+        ctx_len = ctx.shape[0]
+        for _ in range(draft_steps):
+            tmp = m.new_cache(ctx_len + bs)
+            p0 = max(0, self.start - ctx_len)
+            c2 = ctx
+            if ctx_len > 16:
+                m.prefill_context(tmp, ctx[:ctx_len - 16], p0)
+                c2, p0 = ctx[ctx_len - 16:], p0 + ctx_len - 16
+            hid = m.draft_block(tmp, th_rows=c2, tau=c2.shape[0], bs=bs, pos0=p0, block_ids=blk[0],
+                                embed=self.embed_w, append=False)
+            _draft_ids(m, hid, self.lm_wp, bs, blk, 0.0)
+            if self.hook is not None:
+                self.hook(blk, self.start, self.hook_calls)
+            self.hook_calls += 1
+
+    @torch.inference_mode()
+    def cycle(self, bs: int, *, draft_steps: int = 1, want_hidden: Optional[bool] = None,
+              after_draft: Optional[Callable] = None) -> SimpleNamespace:
+        """One pass of model/dflash.py:235-268 with block size `bs` (>= 1)."""
+        start = self.start
+        blk = self.block[:, :bs]
+        blk.copy_(self.output_ids[:, start:start + bs])
+        if bs > 1:
+            self._mark("draft", 0)
+            self._draft(blk, bs, draft_steps)
+            self._mark("draft", 1)
+            if after_draft is not None:
+                after_draft(blk)
+        if want_hidden is None:
+            want_hidden = self.use_draft
+        # ---- target verify (outside the path; model/dflash.py:249-255)
+        self._mark("target", 0)
+        out = self.target(blk, position_ids=self.position_ids[:, start:start + bs], past_key_values=self.tcache,
+                          use_cache=True, output_hidden_states=want_hidden)
+        self._mark("target", 1)
+        posterior = sample(out.logits, self.temperature)
+        # ---- accept scan + commit + bookkeeping on the device (:258-268)
+        ops.set_dyn(self.dyn, 0, 0, bs, start)  # start word = pos0 + tau = start
+        ops.accept_commit(blk[0], posterior[0].contiguous(), bs, self.output_ids[0], self.dyn, self.stop_t,
+                          self.result)
+        res = self.result.tolist()  # the cycle's one device->host read (synchronises the stream)
+        tau = res[0] + 1
+        self.start = start + tau
+        self.tcache.crop(self.start)
+        if want_hidden and self.use_draft:
+            self.target_hidden = _taps(out.hidden_states, self.model.target_layer_ids)[:, :tau, :]
+        self.stopped = bool(self.stop_always or res[2])
+        return SimpleNamespace(tau=tau, bs=bs, start=start, stop=self.stopped)
+
+    def finish(self) -> torch.Tensor:
+        return _trim(self.output_ids, self.max_length, self.mask_token_id, self.stop_token_ids, self.n_in)
+
+
+@torch.inference_mode()
+def run_decode(model, target, input_ids: torch.Tensor, *, mask_token_id: int, max_new_tokens: int,
+               block_size: int, stop_token_ids, temperature: float, clamp_tail: bool,
+               draft_steps: int = 1, collect_profile: bool = False, scheduler=None,
+               draft_temperature: float = 0.0, draft_token_hook: Optional[Callable] = None,
+               max_block_size: Optional[int] = None) -> SimpleNamespace:
+    s = DecodeSession(model, target, input_ids, mask_token_id=mask_token_id, max_new_tokens=max_new_tokens,
+                      max_block_size=max_block_size or block_size, stop_token_ids=stop_token_ids,
+                      temperature=temperature, draft_temperature=draft_temperature,
+                      draft_token_hook=draft_token_hook)
+    t_prefill = cuda_time()
+    s.prefill()
+    time_to_first_token = cuda_time() - t_prefill
+
+    decode_start = cuda_time()
+    taus, used_bs, cycle_trace, lgens = [], [], [], []
+    draft_prefill = True
+    cyc = 0
+    while s.start < s.max_length:
+        cycle_t0 = cuda_time() if scheduler is not None else None
+        if collect_profile:
+            s.events = {}
+            s._mark("cycle", 0)
+        chosen = block_size if scheduler is None else scheduler.select(cyc)
+        remaining = s.max_length - s.start
+        bs = max(1, min(chosen, remaining)) if (clamp_tail or scheduler is not None) else chosen
+        lg = [float(bs)]
+
+        def after_draft(blk, lg=lg, bs=bs):
+            # EOS-aware generated length of the policy loop (benchmark_dynamic_schedule.py:344-349)
+            if scheduler is not None and s.stop_t is not None:
+                pos = torch.isin(blk[0, 1:], s.stop_t).nonzero(as_tuple=True)[0]
+                if pos.numel() > 0:
+                    lg[0] = float(min(int(pos[0].item()) + 1, bs))
+
+        # hidden states: always in spec_generate / the policy loop, only for bs > 1 in the
+        # harness form (benchmark.py:157)
+        want_hidden = s.use_draft if (scheduler is not None or not clamp_tail) else bs > 1
+        gen_before = s.start - s.n_in
+        start_idx = s.start
+        r = s.cycle(bs, draft_steps=draft_steps, want_hidden=want_hidden, after_draft=after_draft)
+        if bs > 1 and draft_prefill:
+            draft_prefill = False
+            decode_start = cuda_time()  # TPOT excludes cycle 0's prompt-context projection (benchmark.py:145-147)
+        taus.append(r.tau)
+        used_bs.append(bs)
+        lgens.append(lg[0])
+        if scheduler is not None:
+            cycle_s = cuda_time() - cycle_t0
+            scheduler.update(tau=r.tau, cycle_s=cycle_s, effective_bs=bs, cycle_idx=cyc, l_gen=lg[0])
+            cycle_trace.append({
+                "cycle_idx": cyc, "start_idx": int(start_idx), "block_size": int(bs),
+                "chosen_block_size": int(chosen), "tau": int(r.tau), "l_gen": float(lg[0]),
+                "acceptance_ratio": float(r.tau / max(1, bs)), "cycle_s": float(cycle_s),
+                "tau_hat": scheduler.tau_hat.get(bs), "cycle_hat": scheduler.cycle_hat.get(bs),
+                "score_hat": scheduler.score_hat.get(bs), "current_block_size": int(scheduler.current),
+                "adl_lgen_hat": scheduler.adl_lgen_hat, "adl_lacc_hat": scheduler.adl_lacc_hat,
+                "adl_target_k": int(scheduler.adl_target_k), "adl_target_bs": int(scheduler.adl_target_bs)})
+        elif collect_profile:
+            s._mark("cycle", 1)
+            cycle_trace.append({"cycle_idx": cyc, "generated_tokens_before": int(gen_before),
+                                "effective_block_size": int(bs), "tau": int(r.tau),
+                                "acceptance_ratio": float(r.tau / max(1, bs)), "_events": s.events})
+        s.events = None
+        cyc += 1
+        if r.stop:
+            break
+
+    output_ids = s.finish()
+    num_output_tokens = output_ids.shape[1] - s.n_in
+    total_decode_time = cuda_time() - decode_start
+    profile_summary = None
+    if collect_profile and scheduler is None:
+        profile_summary = _resolve_profile(cycle_trace, time_to_first_token, total_decode_time)
+    return SimpleNamespace(output_ids=output_ids, num_input_tokens=s.n_in, num_output_tokens=num_output_tokens,
+                           time_to_first_token=time_to_first_token,
+                           time_per_output_token=total_decode_time / max(1, num_output_tokens),
+                           acceptance_lengths=taus, used_block_sizes=used_bs, l_gen=lgens,
+                           cycle_trace=cycle_trace, profile_summary=profile_summary)
 
 
 def _draft_ids(model, hid_frag, lm_wp, bs, blk, draft_temperature):
@@ -253,8 +300,8 @@ def _resolve_profile(cycle_trace, ttft, decode_wall):
     for row in cycle_trace:
         ev = row.pop("_events")
         for k in tot:
-            a, b = ev[k]
-            s = a.elapsed_time(b) / 1000.0 if (k != "draft" or row["effective_block_size"] > 1) else 0.0
+            pair = ev.get(k)
+            s = pair[0].elapsed_time(pair[1]) / 1000.0 if pair and pair[0] is not None and pair[1] is not None else 0.0
             row[f"{k}_s"] = float(s)
             tot[k] += s
     den = max(1e-12, tot["draft"] + tot["target"])
@@ -304,7 +351,6 @@ class _Fixed:
     """fixed_block_size path of dflash_generate_policy: a scheduler that never moves."""
     candidates = ()
     tau_hat = cycle_hat = score_hat = {}
-    current = adl_target_k = adl_target_bs = 0
     adl_lgen_hat = adl_lacc_hat = None
 
     def __init__(self, bs):

@@ -26,24 +26,28 @@ from .dflash_oracle import ListKVCache, apply_rotary_std, attention, rms_norm, r
 
 
 class _Inner(nn.Module):
-    def __init__(self, vocab: int, hidden: int):
+    def __init__(self, vocab: int, hidden: int, weight=None):
         super().__init__()
-        self.embed_tokens = nn.Embedding(vocab, hidden)
+        self.embed_tokens = nn.Embedding(vocab, hidden, _weight=weight)
 
 
 class TorchQwen3Target(nn.Module):
     def __init__(self, *, vocab_size: int, hidden_size: int, num_layers: int, num_heads: int,
                  num_kv_heads: int, head_dim: int, intermediate_size: int, rms_norm_eps: float = 1e-6,
                  rope_theta: float = 1e6, attn_impl: str = "eager", init_std: float = 0.02,
-                 seed: Optional[int] = None, dtype=torch.float32, device="cpu"):
+                 seed: Optional[int] = None, dtype=torch.float32, device="cpu", fill_fn=None):
         super().__init__()
         self.cfg = SimpleNamespace(vocab_size=vocab_size, hidden_size=hidden_size, num_hidden_layers=num_layers,
                                    num_attention_heads=num_heads, num_key_value_heads=num_kv_heads,
                                    head_dim=head_dim, intermediate_size=intermediate_size,
                                    rms_norm_eps=rms_norm_eps, rope_theta=rope_theta)
         self.attn_impl = attn_impl
-        self.model = _Inner(vocab_size, hidden_size)
-        self.lm_head = nn.Linear(hidden_size, vocab_size, bias=False)
+        # fill_fn(shape) -> tensor: cheap deterministic fill for big timing-only models
+        # (bench.py's CPU baseline); default is seeded N(0, init_std)
+        self.model = _Inner(vocab_size, hidden_size, None if fill_fn is None else fill_fn((vocab_size, hidden_size)))
+        self.lm_head = nn.Linear(hidden_size, vocab_size, bias=False, device="meta" if fill_fn else None)
+        if fill_fn is not None:
+            self.lm_head.weight = nn.Parameter(fill_fn((vocab_size, hidden_size)), requires_grad=False)
         H, D, I = hidden_size, head_dim, intermediate_size
         shapes = {"self_attn.q_proj.weight": (num_heads * D, H), "self_attn.k_proj.weight": (num_kv_heads * D, H),
                   "self_attn.v_proj.weight": (num_kv_heads * D, H), "self_attn.o_proj.weight": (H, num_heads * D),
@@ -54,13 +58,15 @@ class TorchQwen3Target(nn.Module):
         self.w = nn.ParameterDict()
         for i in range(num_layers):
             for k, s in shapes.items():
-                self.w[f"{i}|{k}".replace(".", "|")] = nn.Parameter(torch.randn(s, generator=g) * init_std)
+                t = fill_fn(s) if fill_fn is not None else torch.randn(s, generator=g) * init_std
+                self.w[f"{i}|{k}".replace(".", "|")] = nn.Parameter(t, requires_grad=False)
             for k, s in ones.items():
                 self.w[f"{i}|{k}".replace(".", "|")] = nn.Parameter(1.0 + 0.1 * torch.randn(s, generator=g))
         self.w["norm"] = nn.Parameter(1.0 + 0.1 * torch.randn(H, generator=g))
-        with torch.no_grad():
-            self.model.embed_tokens.weight.copy_(torch.randn(vocab_size, H, generator=g) * init_std)
-            self.lm_head.weight.copy_(torch.randn(vocab_size, H, generator=g) * init_std)
+        if fill_fn is None:
+            with torch.no_grad():
+                self.model.embed_tokens.weight.copy_(torch.randn(vocab_size, H, generator=g) * init_std)
+                self.lm_head.weight.copy_(torch.randn(vocab_size, H, generator=g) * init_std)
         self.requires_grad_(False)
         self.to(device=device, dtype=dtype)
         self.eval()
