@@ -11,11 +11,21 @@ temperature 0.  A *step* is one decode cycle: draft block forward + fused lm_hea
 (HIP), target verify (PyTorch), posterior argmax + accept/commit (HIP).
 
 Random weights never agree (tau == 1), so acceptance is scripted as SURVEY.md §8d
-prescribes: the target's greedy continuation G is computed beforehand (untimed) and,
-after the fully timed draft forward + argmax, the draft tokens are overwritten with
+prescribes: the target's greedy continuation G is known beforehand and, after the
+fully timed draft forward + argmax, the draft tokens are overwritten with
 G[start+1 : start+k] followed by a wrong id, k drawn from a seeded truncated-geometric
 law whose mean tau matches the published 7.3.  `value` is committed tokens / wall time
 over all ranks; `raw_tau1_value` is the same cycles counted at tau = 1.
+
+A plainly random-init bf16 target has near-zero top-2 logit margins: its argmax flips
+between a 1-token and a 16-token forward (measured: 65 % of tokens reproduced), so no
+greedy tape survives the verify.  The synthetic target is therefore given a large-margin
+greedy rule WITHOUT changing its architecture, byte count or FLOPs: seeded random
+weights, embedding std 1.0, o_proj/down_proj scaled by 0.02 (the residual stream stays
+embedding-dominated through all 36 layers), lm_head = 0.02 * embedding rows permuted by
+a seeded single-cycle permutation.  Its greedy next token is perm[token] with a logit
+margin ~70, so G is a closed-form walk and `lossless_fraction` (committed ids == G)
+must read 1.0.
 
 N > 1: every rank runs its own request (weak scaling, no collective on the accept path;
 one all-reduce of the timing/token scalars after the timed region).
@@ -56,7 +66,23 @@ def make_hf_target(dev, layers=36):
             m = Qwen3ForCausalLM(cfg)
     finally:
         torch.set_default_dtype(prev)
-    return m.eval()
+    # large-margin greedy rule (see module docstring); values stay seeded-random
+    g = torch.Generator(device=dev).manual_seed(1234)
+    V, H = T["vocab_size"], T["hidden_size"]
+    cyc = torch.randperm(V, generator=g, device=dev)
+    perm = torch.empty(V, dtype=torch.long, device=dev)
+    perm[cyc] = torch.roll(cyc, -1)               # one cycle through the whole vocabulary
+    with torch.no_grad():
+        emb = torch.randn(V, H, generator=g, device=dev, dtype=torch.float32)
+        m.model.embed_tokens.weight.copy_(emb)
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(V, device=dev)
+        m.lm_head.weight.copy_(emb[inv] * 0.02)   # row perm[t] = 0.02 * embed[t]
+        del emb
+        for layer in m.model.layers:
+            layer.self_attn.o_proj.weight.mul_(0.02)
+            layer.mlp.down_proj.weight.mul_(0.02)
+    return m.eval(), perm
 
 
 def tau_plan(n, bs, seed, mean_tau=7.3):
@@ -80,7 +106,7 @@ def gpu_leg(args, rank, world, dev):
 
     torch.manual_seed(0)
     t0 = time.time()
-    target = make_hf_target(dev, layers=args.target_layers)
+    target, perm = make_hf_target(dev, layers=args.target_layers)
     cfg = DFlashConfig(**{**QWEN3_8B_DRAFT, "num_target_layers": args.target_layers})
     draft = DFlashDraftModel(cfg, device=dev)
     # seeded init directly on the GPU (CPU generation of 1e9 normals costs a minute)
@@ -100,16 +126,13 @@ def gpu_leg(args, rank, world, dev):
     need = sum(k + 1 for k in plan[:ncyc]) + 2 * bs
     mask_id = cfg.mask_token_id
 
-    # ---- untimed: the target's own greedy continuation G (pure AR, block size 1)
-    t0 = time.time()
-    ar = DecodeSession(draft, target, prompt, mask_token_id=mask_id, max_new_tokens=need, max_block_size=1,
-                       stop_token_ids=None, temperature=0.0)
-    ar.prefill()
-    while ar.start < ar.max_length:
-        ar.cycle(1, want_hidden=False)
-    G = ar.output_ids[0].clone()
-    del ar
-    log(f"[rank {rank}] greedy tape of {need} tokens in {time.time() - t0:.1f}s")
+    # ---- the target's greedy continuation G in closed form: G[p+1] = perm[G[p]]
+    G = torch.full((P + need + 2 * bs,), -1, dtype=torch.long)
+    G[:P] = prompt[0].cpu()
+    pc = perm.cpu()
+    for p in range(P, G.numel()):
+        G[p] = pc[G[p - 1]]
+    G = G.to(dev)
 
     def hook(blk, start, call):
         k = plan[call]
@@ -151,15 +174,13 @@ def gpu_leg(args, rank, world, dev):
     n_ok = int((s.output_ids[0, P:s.start] == G[P:s.start]).sum())
     lossless = n_ok / max(1, s.start - P)
 
-    stats = torch.tensor([dt, float(tokens), float(args.steps)], dtype=torch.float64, device=dev)
-    if world > 1:
-        mx = stats.clone()
-        torch.distributed.all_reduce(mx, op=torch.distributed.ReduceOp.MAX)
-        sm = stats.clone()
-        torch.distributed.all_reduce(sm, op=torch.distributed.ReduceOp.SUM)
-        dt_max, tok_sum, cyc_sum = float(mx[0]), float(sm[1]), float(sm[2])
-    else:
-        dt_max, tok_sum, cyc_sum = dt, float(tokens), float(args.steps)
+    from dflash_amd import distributed as D
+    dt_max, tok_sum = D.reduce_timing(dt, float(tokens), device=dev)
+    _, cyc_sum = D.reduce_timing(dt, float(args.steps), device=dev)
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r1_pmc_lm_head.json")
+    if os.path.exists(pmc):  # PMC passes cannot run inside the timed bench: committed summary of the same kernel
+        traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
     kv_bytes = 20480 * (P + 16)
     hot_bytes = DRAFT_WEIGHT_BYTES + LM_HEAD_BYTES + kv_bytes
     return dict(
@@ -167,9 +188,11 @@ def gpu_leg(args, rank, world, dev):
         raw_tau1_value=cyc_sum / dt_max, lossless_fraction=lossless,
         roofline={"kernel": "k_gemm<1,8,EPI_ARGMAX> (lm_head GEMM + fused argmax)", "bound": "hbm",
                   "achieved": LM_HEAD_BYTES / (lm_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                  "frac": LM_HEAD_BYTES / (lm_ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
+                  "frac": LM_HEAD_BYTES / (lm_ms * 1e-3) / 1e9 / 8000.0, "traffic": traffic,
                   "bytes_per_launch": LM_HEAD_BYTES, "avg_ms": lm_ms,
-                  "note": "event pair also spans the 16-wave argmax finish kernel"},
+                  "note": "achieved/avg_ms from stream events around the launch in the timed region (the pair also "
+                          "spans the 16-wave argmax finish kernel); traffic = 2*FETCH_SIZE+WRITE_SIZE bytes from "
+                          "profiles/r1_pmc_summary.csv"},
         hot_path={"draft_plus_lm_head_ms_per_cycle": draft_ms, "target_verify_ms_per_cycle": target_ms,
                   "algorithmic_bytes_per_cycle": hot_bytes,
                   "achieved_GBps": hot_bytes / (draft_ms * 1e-3) / 1e9,

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun): rocprofv3 passes over bench.py.
+#   scripts/profile_gpu.sh stats   -> kernel trace + stats of the default-shaped bench command
+#   scripts/profile_gpu.sh pmc     -> FETCH_SIZE and WRITE_SIZE passes (separate runs, no other tracing)
+# Output under gpurun_out/; summaries worth judging are copied into profiles/ by hand.
+set -u
+R=${GRAFT_REPO_ROOT:-$PWD}
+mkdir -p "$R/gpurun_out"
+cd /tmp && export TMPDIR=/tmp
+mode=${1:-stats}
+if [ "$mode" = stats ]; then
+  timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_stats" -- \
+    python3 "$R/bench.py" --steps 24 --warmup 2 --no-cpu-baseline > "$R/gpurun_out/prof_stats.json" 2> "$R/gpurun_out/prof_stats.err"
+  echo "stats rc=$?"
+else
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$R/gpurun_out/pmc_$c" -- \
+      python3 "$R/bench.py" --steps 6 --warmup 1 --no-cpu-baseline --target-layers 2 > "$R/gpurun_out/pmc_$c.json" 2> "$R/gpurun_out/pmc_$c.err"
+    rc=$?
+    echo "pmc $c rc=$rc"
+    [ $rc -ne 0 ] && { tail -5 "$R/gpurun_out/pmc_$c.err"; exit $rc; }
+  done
+fi
+ls -R "$R/gpurun_out" | head -40
