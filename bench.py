@@ -50,39 +50,10 @@ def log(*a):
 
 
 def make_hf_target(dev, layers=36):
-    from transformers import Qwen3Config, Qwen3ForCausalLM
     from dflash_amd.config import QWEN3_8B_TARGET as T
-    cfg = Qwen3Config(vocab_size=T["vocab_size"], hidden_size=T["hidden_size"],
-                      intermediate_size=T["intermediate_size"], num_hidden_layers=layers,
-                      num_attention_heads=T["num_heads"], num_key_value_heads=T["num_kv_heads"],
-                      head_dim=T["head_dim"], max_position_embeddings=40960, rms_norm_eps=1e-6,
-                      rope_parameters={"rope_type": "default", "rope_theta": T["rope_theta"]},
-                      tie_word_embeddings=False, attention_bias=False)
-    cfg._attn_implementation = "sdpa"
-    prev = torch.get_default_dtype()
-    torch.set_default_dtype(torch.bfloat16)
-    try:
-        with torch.device(dev):
-            m = Qwen3ForCausalLM(cfg)
-    finally:
-        torch.set_default_dtype(prev)
-    # large-margin greedy rule (see module docstring); values stay seeded-random
-    g = torch.Generator(device=dev).manual_seed(1234)
-    V, H = T["vocab_size"], T["hidden_size"]
-    cyc = torch.randperm(V, generator=g, device=dev)
-    perm = torch.empty(V, dtype=torch.long, device=dev)
-    perm[cyc] = torch.roll(cyc, -1)               # one cycle through the whole vocabulary
-    with torch.no_grad():
-        emb = torch.randn(V, H, generator=g, device=dev, dtype=torch.float32)
-        m.model.embed_tokens.weight.copy_(emb)
-        inv = torch.empty_like(perm)
-        inv[perm] = torch.arange(V, device=dev)
-        m.lm_head.weight.copy_(emb[inv] * 0.02)   # row perm[t] = 0.02 * embed[t]
-        del emb
-        for layer in m.model.layers:
-            layer.self_attn.o_proj.weight.mul_(0.02)
-            layer.mlp.down_proj.weight.mul_(0.02)
-    return m.eval(), perm
+    from dflash_amd.synthetic import impose_greedy_walk, make_hf_qwen3
+    m = make_hf_qwen3({**T, "num_layers": layers}, dev)
+    return m, impose_greedy_walk(m, seed=1234)   # large-margin greedy rule, see module docstring
 
 
 def tau_plan(n, bs, seed, mean_tau=7.3):
@@ -107,6 +78,9 @@ def gpu_leg(args, rank, world, dev):
     torch.manual_seed(0)
     t0 = time.time()
     target, perm = make_hf_target(dev, layers=args.target_layers)
+    if not args.hf_verify:
+        from dflash_amd import NativeTarget
+        target = NativeTarget(target)   # verify on the kernels, prefill through HF
     cfg = DFlashConfig(**{**QWEN3_8B_DRAFT, "num_target_layers": args.target_layers})
     draft = DFlashDraftModel(cfg, device=dev)
     # seeded init directly on the GPU (CPU generation of 1e9 normals costs a minute)
@@ -127,12 +101,8 @@ def gpu_leg(args, rank, world, dev):
     mask_id = cfg.mask_token_id
 
     # ---- the target's greedy continuation G in closed form: G[p+1] = perm[G[p]]
-    G = torch.full((P + need + 2 * bs,), -1, dtype=torch.long)
-    G[:P] = prompt[0].cpu()
-    pc = perm.cpu()
-    for p in range(P, G.numel()):
-        G[p] = pc[G[p - 1]]
-    G = G.to(dev)
+    from dflash_amd.synthetic import greedy_walk
+    G = greedy_walk(perm, prompt, need + 2 * bs).to(dev)
 
     def hook(blk, start, call):
         k = plan[call]
@@ -282,6 +252,9 @@ def main():
     ap.add_argument("--target-layers", type=int, default=36)
     ap.add_argument("--cpu-cycles", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--hf-verify", action="store_true",
+                    help="verify through the HF/PyTorch target forward (round-1 configuration) instead of "
+                         "dflash_amd.NativeTarget")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -308,10 +281,12 @@ def main():
             "metric": "accepted_tokens_per_sec", "value": res["value"], "unit": "tokens/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "Qwen3-8B-shaped target (HF, PyTorch-ROCm) + DFlash-b16 5-layer draft, "
+            "config": {"workload": "Qwen3-8B-shaped target (" + ("HF/PyTorch-ROCm verify" if args.hf_verify else
+                                   "HF prefill, NativeTarget verify on the kernels") + ") + DFlash-b16 5-layer draft, "
                                    f"block=16, temp=0, batch=1 per GPU, prefix={args.prefix}, random-init weights, "
                                    "scripted acceptance (seeded truncated-geometric, mean tau 7.3)",
-                       "target_layers": args.target_layers, "requests": world, "parallelism": f"dp{world}"},
+                       "target_layers": args.target_layers, "requests": world,
+                       "target_verify": "hf" if args.hf_verify else "native", "parallelism": f"dp{world}"},
             "mean_acceptance_length": res["mean_tau"], "raw_tau1_value": res["raw_tau1_value"],
             "lossless_fraction": res["lossless_fraction"], "roofline": res["roofline"], "hot_path": res["hot_path"],
             "cpu_baseline": cpu,

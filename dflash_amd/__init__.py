@@ -14,7 +14,8 @@ from .utils import build_target_layer_ids, extract_context_feature, sample
 from .scheduler import EWMAPerformanceScheduler
 from .model import DFlashDraftModel, DFlashKVCache
 from .generate import dflash_generate, dflash_generate_policy
+from .target import NativeTarget
 
 __all__ = ["DFlashConfig", "DFlashDraftModel", "DFlashKVCache", "EWMAPerformanceScheduler",
            "build_target_layer_ids", "extract_context_feature", "sample", "dflash_generate",
-           "dflash_generate_policy"]
+           "dflash_generate_policy", "NativeTarget"]

@@ -24,11 +24,11 @@ SIGNATURES = {
     "dfl_gemm_silu_mul": (_i, [_p, _p, _i, _i, _p, _p]),
     "dfl_argmax_ws_bytes": (_i64, []),
     "dfl_gemm_argmax": (_i, [_p, _p, _i, _i, _i, _i, _p, _i, _p, _p, _i, _p, _p]),
-    "dfl_norm_pack": (_i, [_p, _i, _i64, _i, _i, _p, _p, _p, _p, _p, _f, _p, _i, _p, _i, _p]),
+    "dfl_norm_pack": (_i, [_p, _i, _i64, _i, _i, _p, _p, _p, _p, _p, _i64, _p, _f, _p, _i, _p, _i, _p]),
     "dfl_qknorm_rope_append": (_i, [_p, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _f, _p, _p, _i, _p, _p, _p, _i, _p,
                                     _i, _i, _p]),
     "dfl_attn_ws_bytes": (_i64, [_i, _i]),
-    "dfl_block_attn": (_i, [_p, _p, _p, _i, _i, _i, _f, _p, _i, _p, _i, _p, _p]),
+    "dfl_block_attn": (_i, [_p, _p, _p, _i, _i, _i, _f, _i, _p, _i, _p, _i, _p, _p]),
     "dfl_argmax": (_i, [_p, _i, _i, _i64, _p, _p]),
     "dfl_accept_commit": (_i, [_p, _p, _i, _p, _i64, _p, _p, _i, _p, _p]),
 }

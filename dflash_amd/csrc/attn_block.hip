@@ -29,6 +29,7 @@ struct AttnArgs {
   int cache_rows;
   int n_q, n_kv, G;
   float scale_log2;
+  int causal;  // 1: query row j sees cache rows <= S + tau + j (target verify); 0: no mask (draft)
   const int32_t *dyn;
   float *o_part;   // [nsplit][n_q][16][128]
   float *ml_part;  // [nsplit][n_q][16][2]
@@ -42,7 +43,8 @@ __global__ __launch_bounds__(512) void k_block_attn(AttnArgs a) {
   const int wv = tid >> 6, l = tid & 63;
   const int kvh = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
   const int head = kvh * a.G + wv;
-  const int kv_len = a.dyn[DFL_DYN_S] + a.dyn[DFL_DYN_TAU] + a.dyn[DFL_DYN_BS];
+  const int qbase = a.dyn[DFL_DYN_S] + a.dyn[DFL_DYN_TAU];  // cache row of the block's first query
+  const int kv_len = qbase + a.dyn[DFL_DYN_BS];
   const int ntiles = (kv_len + 31) >> 5;
   const int tps = (ntiles + nsplit - 1) / nsplit;
   const int t0 = split * tps;
@@ -96,14 +98,19 @@ __global__ __launch_bounds__(512) void k_block_attn(AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = t * 32 + u * 16 + 4 * g + r;
-        const float v = key < kv_len ? sc[u][r] * a.scale_log2 : -INFINITY;
+        const bool vis = key < kv_len && (!a.causal || key <= qbase + qi);
+        const float v = vis ? sc[u][r] * a.scale_log2 : -INFINITY;
         sc[u][r] = v;
         mx = fmaxf(mx, v);
       }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);  // finite: every tile in range holds >= 1 valid key
-    const float alpha = exp2f(m_run - m_new);
+    // no mask: every tile in range holds >= 1 valid key, m_new is finite.  causal: a query
+    // may see nothing of an early split's tile; keep -inf as the running max but never
+    // form (-inf) - (-inf).
+    const float m_new = fmaxf(m_run, mx);
+    const float m_ref = m_new == -INFINITY ? 0.f : m_new;
+    const float alpha = exp2f(m_run - m_ref);
     m_run = m_new;
     float psum = 0.f;
     bf16x8 pb;
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(512) void k_block_attn(AttnArgs a) {
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = exp2f(sc[u][r] - m_new);
+        const float p = exp2f(sc[u][r] - m_ref);
         psum += p;
         pb[u * 4 + r] = f2bf(p);
       }
@@ -187,8 +194,8 @@ extern "C" int64_t dfl_attn_ws_bytes(int n_q, int max_splits) {
 }
 
 extern "C" int dfl_block_attn(const void *q, const void *kcache, const void *vcache, int cache_rows, int n_q, int n_kv,
-                              float scale, const int32_t *dyn, int kv_len_max, void *ws, int max_splits,
-                              void *out_frag, void *stream) {
+                              float scale, int causal, const int32_t *dyn, int kv_len_max, void *ws,
+                              int max_splits, void *out_frag, void *stream) {
   DFL_REQUIRE(q && kcache && vcache && dyn && ws && out_frag, "dfl_block_attn: null pointer");
   DFL_REQUIRE(n_q > 0 && n_kv > 0 && n_q % n_kv == 0 && n_q / n_kv <= 8, "dfl_block_attn: GQA group must be 1..8 (n_q=%d n_kv=%d)",
               n_q, n_kv);
@@ -207,6 +214,7 @@ extern "C" int dfl_block_attn(const void *q, const void *kcache, const void *vca
   a.n_kv = n_kv;
   a.G = n_q / n_kv;
   a.scale_log2 = scale * 1.4426950408889634f;
+  a.causal = causal ? 1 : 0;
   a.dyn = dyn;
   a.o_part = (float *)ws;
   a.ml_part = (float *)ws + (int64_t)max_splits * n_q * 16 * 128;

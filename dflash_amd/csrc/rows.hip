@@ -43,6 +43,8 @@ struct NormArgs {
   const bf16_t *embed;
   const int64_t *ids;
   bf16_t *h_out;
+  bf16_t *h_out2;  // optional second copy of the residual row (target taps), row stride ld2
+  int64_t ld2;
   const bf16_t *norm_w;
   float eps;
   bf16x8 *frag;
@@ -107,6 +109,7 @@ __global__ __launch_bounds__(256) void k_norm_pack(NormArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = f2bf(h[i][j]);
         *reinterpret_cast<bf16x8 *>(a.h_out + (int64_t)m * a.H + c * 8) = o;
+        if (a.h_out2) *reinterpret_cast<bf16x8 *>(a.h_out2 + (int64_t)m * a.ld2 + c * 8) = o;
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) ss += h[i][j] * h[i][j];
@@ -209,11 +212,14 @@ __global__ __launch_bounds__(256) void k_qknorm_rope(RopeArgs a) {
     return;
   }
   // Qwen3RMSNorm over head_dim (model/dflash.py:72,79)
-  const float ss = wave_sum(x1 * x1 + x2 * x2);
-  const float rstd = rsqrtf(ss * (1.f / 128.f) + a.eps);
   const bf16_t *nw = kind == 0 ? a.q_w : a.k_w;
-  const float n1 = rbf(bf2f(nw[l]) * rbf(x1 * rstd));
-  const float n2 = rbf(bf2f(nw[l + 64]) * rbf(x2 * rstd));
+  float n1 = x1, n2 = x2;
+  if (nw) {  // Qwen3 has per-head q/k norms, Llama does not
+    const float ss = wave_sum(x1 * x1 + x2 * x2);
+    const float rstd = rsqrtf(ss * (1.f / 128.f) + a.eps);
+    n1 = rbf(bf2f(nw[l]) * rbf(x1 * rstd));
+    n2 = rbf(bf2f(nw[l + 64]) * rbf(x2 * rstd));
+  }
   // RoPE, model/dflash.py:22-28: (x*cos) + (rotate_half(x)*sin), each product and the
   // sum rounded to bf16 as torch's elementwise bf16 ops do.
   int pos = pos0 + rel;
@@ -257,15 +263,16 @@ extern "C" int dfl_pack_rows(const void *x, int64_t ldx, int rows, int K, void *
 
 extern "C" int dfl_norm_pack(const float *part, int nsplit, int64_t part_split, int ldp, int row_off,
                              const void *resid_in, const void *embed, const int64_t *ids, void *h_out,
-                             const void *norm_w, float eps, void *frag, int H, const int32_t *dyn, int dyn_word,
-                             void *stream) {
+                             void *h_out2, int64_t ld2, const void *norm_w, float eps, void *frag, int H,
+                             const int32_t *dyn, int dyn_word, void *stream) {
   DFL_REQUIRE(norm_w && frag, "dfl_norm_pack: null norm_w/frag");
   DFL_REQUIRE(part || resid_in || embed, "dfl_norm_pack: no input");
   DFL_REQUIRE(!(embed && !ids), "dfl_norm_pack: embed without ids");
   DFL_REQUIRE(H > 0 && H % 8 == 0 && H <= 16384, "dfl_norm_pack: H=%d unsupported", H);
   DFL_REQUIRE(!part || (nsplit >= 1 && ldp % 4 == 0), "dfl_norm_pack: bad partial layout");
+  DFL_REQUIRE(!h_out2 || (h_out && ld2 % 8 == 0), "dfl_norm_pack: h_out2 needs h_out and ld2%%8==0");
   NormArgs a{part, nsplit, part_split, ldp, row_off, (const bf16_t *)resid_in, (const bf16_t *)embed, ids,
-             (bf16_t *)h_out, (const bf16_t *)norm_w, eps, (bf16x8 *)frag, H, dyn, dyn_word};
+             (bf16_t *)h_out, (bf16_t *)h_out2, ld2, (const bf16_t *)norm_w, eps, (bf16x8 *)frag, H, dyn, dyn_word};
   const int nchunks = H / 8;
   if (nchunks <= 512)
     hipLaunchKernelGGL(k_norm_pack<2>, dim3(16), dim3(256), 0, (hipStream_t)stream, a);
@@ -282,8 +289,8 @@ extern "C" int dfl_qknorm_rope_append(const float *qkv, int nsplit, int64_t spli
                                       const void *k_norm_w, float eps, const void *cos_tab, const void *sin_tab,
                                       int max_pos, void *q_out, void *kcache, void *vcache, int cache_rows,
                                       const int32_t *dyn, int ctx_rows_override, int row_base, void *stream) {
-  DFL_REQUIRE(qkv && q_norm_w && k_norm_w && cos_tab && sin_tab && kcache && vcache && dyn,
-              "dfl_qknorm_rope_append: null pointer");
+  DFL_REQUIRE(qkv && cos_tab && sin_tab && kcache && vcache && dyn, "dfl_qknorm_rope_append: null pointer");
+  DFL_REQUIRE((q_norm_w == nullptr) == (k_norm_w == nullptr), "dfl_qknorm_rope_append: give both norm weights or neither");
   DFL_REQUIRE(q_col < 0 || q_out, "dfl_qknorm_rope_append: q wanted but q_out is null");
   DFL_REQUIRE(nsplit >= 1 && n_q > 0 && n_kv > 0 && n_q % n_kv == 0, "dfl_qknorm_rope_append: bad head counts");
   DFL_REQUIRE(ctx_rows_override <= 16, "dfl_qknorm_rope_append: at most 16 context rows per call");

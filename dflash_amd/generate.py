@@ -91,12 +91,17 @@ class DecodeSession:
         self.max_length = self.n_in + max_new_tokens
         self.output_ids = torch.full((1, self.max_length + self.max_bs), mask_token_id, dtype=torch.long, device=dev)
         self.position_ids = torch.arange(self.output_ids.shape[1], device=dev).unsqueeze(0)
-        self.tcache = _new_target_cache(target)
+        from .target import NativeTarget
+        self.native = isinstance(target, NativeTarget)
+        self.tcache = (target.new_cache(self.max_length + 2 * self.max_bs) if self.native
+                       else _new_target_cache(target))
         self.use_draft = self.max_bs > 1
         self.dcache = model.new_cache(self.max_length + 2 * self.max_bs) if self.use_draft else None
         self.dyn = self.dcache.dyn if self.dcache is not None else torch.zeros(8, dtype=torch.int32, device=dev)
         self.embed_w = _bf16_table(target.model.embed_tokens.weight, dev)
         self.lm_wp = model.packed_lm_head(target.lm_head) if self.use_draft else None
+        if self.native and self.lm_wp is not None:
+            target.share_lm_head(self.lm_wp)  # one packed copy serves draft unmask and target posterior
         self.stop_t = torch.tensor(stop_token_ids, dtype=torch.long, device=dev) if stop_token_ids else None
         # the reference scans the whole buffer, mask slots included (model/dflash.py:265-268)
         self.stop_always = stop_token_ids is not None and mask_token_id in stop_token_ids
@@ -111,9 +116,12 @@ class DecodeSession:
     @torch.inference_mode()
     def prefill(self) -> None:
         """model/dflash.py:218-229."""
-        out = self.target(self.input_ids, position_ids=self.position_ids[:, :self.n_in],
-                          past_key_values=self.tcache, use_cache=True, logits_to_keep=1,
-                          output_hidden_states=self.use_draft)
+        if self.native:
+            out = self.target.prefill(self.input_ids, self.tcache, output_hidden_states=self.use_draft)
+        else:
+            out = self.target(self.input_ids, position_ids=self.position_ids[:, :self.n_in],
+                              past_key_values=self.tcache, use_cache=True, logits_to_keep=1,
+                              output_hidden_states=self.use_draft)
         self.output_ids[:, :self.n_in] = self.input_ids
         self.output_ids[:, self.n_in:self.n_in + 1] = sample(out.logits, self.temperature)
         if self.use_draft:
@@ -177,10 +185,17 @@ class DecodeSession:
             want_hidden = self.use_draft
         # ---- target verify (outside the path; model/dflash.py:249-255)
         self._mark("target", 0)
-        out = self.target(blk, position_ids=self.position_ids[:, start:start + bs], past_key_values=self.tcache,
-                          use_cache=True, output_hidden_states=want_hidden)
-        self._mark("target", 1)
-        posterior = sample(out.logits, self.temperature)
+        taps = None
+        if self.native:
+            posterior, taps = self.target.verify(
+                blk[0], start, self.tcache, temperature=self.temperature,
+                tap_layers=self.model.target_layer_ids if (want_hidden and self.use_draft) else ())
+            self._mark("target", 1)
+        else:
+            out = self.target(blk, position_ids=self.position_ids[:, start:start + bs],
+                              past_key_values=self.tcache, use_cache=True, output_hidden_states=want_hidden)
+            self._mark("target", 1)
+            posterior = sample(out.logits, self.temperature)
         # ---- accept scan + commit + bookkeeping on the device (:258-268)
         ops.set_dyn(self.dyn, 0, 0, bs, start)  # start word = pos0 + tau = start
         ops.accept_commit(blk[0], posterior[0].contiguous(), bs, self.output_ids[0], self.dyn, self.stop_t,
@@ -190,7 +205,8 @@ class DecodeSession:
         self.start = start + tau
         self.tcache.crop(self.start)
         if want_hidden and self.use_draft:
-            self.target_hidden = _taps(out.hidden_states, self.model.target_layer_ids)[:, :tau, :]
+            self.target_hidden = (taps[None, :tau] if self.native
+                                  else _taps(out.hidden_states, self.model.target_layer_ids)[:, :tau, :])
         self.stopped = bool(self.stop_always or res[2])
         return SimpleNamespace(tau=tau, bs=bs, start=start, stop=self.stopped)
 

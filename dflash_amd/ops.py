@@ -94,9 +94,14 @@ def gemm_argmax(wp, xf, V: int, K: int, row0: int, nrows: int, ws, out_ids: torc
 
 
 def norm_pack(*, norm_w, frag, H: int, eps: float, part=None, nsplit=0, part_split=0, ldp=0, row_off=0,
-              resid_in=None, embed=None, ids=None, h_out=None, dyn=None, dyn_word=0) -> None:
+              resid_in=None, embed=None, ids=None, h_out=None, h_out2=None, ld2=0, dyn=None, dyn_word=0) -> None:
+    # h_out2 may be a column slice of a wider row-major buffer: only its base pointer and ld2 are used
+    p2 = None
+    if h_out2 is not None:
+        assert h_out2.is_cuda and h_out2.dtype == BF16 and h_out2.stride(-1) == 1
+        p2 = h_out2.data_ptr()
     check(lib().dfl_norm_pack(_p(part, F32, "part"), nsplit, part_split, ldp, row_off, _p(resid_in, BF16, "resid_in"),
-                              _p(embed, BF16, "embed"), _p(ids, I64, "ids"), _p(h_out, BF16, "h_out"),
+                              _p(embed, BF16, "embed"), _p(ids, I64, "ids"), _p(h_out, BF16, "h_out"), p2, ld2,
                               _p(norm_w, BF16, "norm_w"), eps, _p(frag, BF16, "frag"), H, _p(dyn, I32, "dyn"),
                               dyn_word, _stream()), "dfl_norm_pack")
 
@@ -117,10 +122,11 @@ def attn_ws(n_q: int, max_splits: int, device) -> torch.Tensor:
     return torch.empty(lib().dfl_attn_ws_bytes(n_q, max_splits), dtype=torch.uint8, device=device)
 
 
-def block_attn(*, q, kcache, vcache, n_q, n_kv, scale, dyn, kv_len_max, ws, max_splits, out_frag) -> None:
+def block_attn(*, q, kcache, vcache, n_q, n_kv, scale, dyn, kv_len_max, ws, max_splits, out_frag,
+               causal: bool = False) -> None:
     check(lib().dfl_block_attn(_p(q, BF16, "q"), _p(kcache, BF16, "kcache"), _p(vcache, BF16, "vcache"),
-                               kcache.shape[1], n_q, n_kv, scale, _p(dyn, I32, "dyn"), kv_len_max, _p(ws),
-                               max_splits, _p(out_frag, BF16, "out_frag"), _stream()), "dfl_block_attn")
+                               kcache.shape[1], n_q, n_kv, scale, int(causal), _p(dyn, I32, "dyn"), kv_len_max,
+                               _p(ws), max_splits, _p(out_frag, BF16, "out_frag"), _stream()), "dfl_block_attn")
 
 
 def argmax(logits: torch.Tensor) -> torch.Tensor:

@@ -1,0 +1,224 @@
+"""`NativeTarget` — the caller-side neighbour of the hot path: the
+target's 16-token *verify* forward (model/dflash.py:249-255) on the same gfx950
+kernels as the draft, over a preallocated target KV cache.
+
+It wraps the caller's HF-style dense causal LM (Qwen3 / Llama layout) and stays
+call-compatible with it: `target(input_ids, position_ids=..., past_key_values=...,
+output_hidden_states=...)`, `.model.embed_tokens`, `.lm_head`, `.device` all forward to
+the wrapped model, so the reference's loop still runs unchanged on it.  The decode
+loops of this package detect it and take the fast path instead:
+
+* prefill (M = prompt length, a plain library GEMM problem) runs through the wrapped
+  model once; its K/V are copied into the preallocated cache;
+* every verify = 36 x {qkv GEMM, q/k-norm + RoPE + append, causal block attention,
+  o_proj, residual + norm, gate/up SiLU GEMM, down GEMM, residual + norm [+ tap copy]}
+  + lm_head GEMM with fused argmax over all 16 rows: the posterior ids come back
+  without materialising 16 x V logits, rollback is a counter, and only the tapped
+  layers' hidden rows are kept (the reference keeps all 37, model/utils.py:16-25).
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Optional, Sequence
+
+import torch
+
+from . import ops
+from .model import _rope_tables
+from .utils import sample
+
+BF16 = torch.bfloat16
+
+
+class TargetKVCache:
+    """Preallocated target KV: [layer][kv head][rows][128] bf16; crop = counter."""
+
+    def __init__(self, n_layers, n_kv, max_rows, device):
+        self.max_rows = int(max_rows)
+        self.k = torch.zeros(n_layers, n_kv, self.max_rows, 128, dtype=BF16, device=device)
+        self.v = torch.zeros_like(self.k)
+        self.dyn = torch.zeros(8, dtype=torch.int32, device=device)
+        self.length = 0
+
+    def get_seq_length(self, layer_idx: int = 0) -> int:
+        return self.length
+
+    def crop(self, max_length: int) -> None:
+        if 0 < max_length < self.length:
+            self.length = int(max_length)
+        elif max_length < 0:
+            self.length = max(0, self.length + int(max_length))
+
+
+class NativeTarget:
+    def __init__(self, hf_model, max_splits: int = 32):
+        cfg = hf_model.config
+        self.hf = hf_model
+        self.model = hf_model.model
+        self.lm_head = hf_model.lm_head
+        self.config = cfg
+        dev = hf_model.lm_head.weight.device
+        if dev.type != "cuda":
+            raise RuntimeError("NativeTarget: the wrapped model must live on the GPU")
+        self._dev = dev
+        self.H = cfg.hidden_size
+        self.L = cfg.num_hidden_layers
+        self.n_q = cfg.num_attention_heads
+        self.n_kv = getattr(cfg, "num_key_value_heads", self.n_q)
+        self.hd = getattr(cfg, "head_dim", None) or self.H // self.n_q
+        self.I = cfg.intermediate_size
+        self.V = cfg.vocab_size
+        self.eps = float(cfg.rms_norm_eps)
+        rope = getattr(cfg, "rope_parameters", None) or {}
+        rtype = rope.get("rope_type", "default") if isinstance(rope, dict) else "default"
+        theta = (rope.get("rope_theta") if isinstance(rope, dict) else None) or getattr(cfg, "rope_theta", None)
+        if self.hd != 128 or self.H // 32 > 128 or self.H % 32 or self.I % 32 or self.V % 16:
+            raise NotImplementedError("NativeTarget: needs head_dim 128, hidden <= 4096 (%32), vocab %16")
+        if rtype != "default" or theta is None:
+            raise NotImplementedError(f"NativeTarget: rope_type {rtype!r} is not supported; keep the HF target")
+        if getattr(cfg, "num_experts", 0) or getattr(cfg, "num_local_experts", 0):
+            raise NotImplementedError("NativeTarget: MoE targets stay on the HF path")
+        if getattr(cfg, "attention_bias", False) or getattr(cfg, "mlp_bias", False):
+            raise NotImplementedError("NativeTarget: biased projections are not supported")
+        self.theta = float(theta)
+        sd = hf_model.state_dict()
+
+        def w(name):
+            return sd[name].detach().to(device=dev, dtype=BF16).contiguous()
+
+        self.layers = []
+        for i in range(self.L):
+            p = f"model.layers.{i}."
+            qkv = torch.cat([w(p + "self_attn.q_proj.weight"), w(p + "self_attn.k_proj.weight"),
+                             w(p + "self_attn.v_proj.weight")], dim=0)
+            has_qk = (p + "self_attn.q_norm.weight") in sd
+            self.layers.append({
+                "qkv": ops.pack_weight(qkv), "o": ops.pack_weight(w(p + "self_attn.o_proj.weight")),
+                "gu": ops.pack_weight_gateup(w(p + "mlp.gate_proj.weight"), w(p + "mlp.up_proj.weight")),
+                "down": ops.pack_weight(w(p + "mlp.down_proj.weight")),
+                "q_norm": w(p + "self_attn.q_norm.weight") if has_qk else None,
+                "k_norm": w(p + "self_attn.k_norm.weight") if has_qk else None,
+                "ln1": w(p + "input_layernorm.weight"), "ln2": w(p + "post_attention_layernorm.weight")})
+            del qkv
+        self.norm = w("model.norm.weight")
+        self.embed = w("model.embed_tokens.weight")
+        self.lm_wp = None  # set by share_lm_head() or packed on first use
+        self.max_splits = max_splits
+        self.q_dim, self.kv_dim = self.n_q * 128, self.n_kv * 128
+        self.nqkv = self.q_dim + 2 * self.kv_dim
+        self.ks_qkv = ops.min_ksplit(self.H, 1)
+        self.ks_o = ops.min_ksplit(self.q_dim, 1)
+        self.ks_down = ops.min_ksplit(self.I, 1)
+        npart = max(self.ks_qkv * 16 * self.nqkv, self.ks_o * 16 * self.H, self.ks_down * 16 * self.H)
+        z = lambda *s, dt=BF16: torch.zeros(*s, dtype=dt, device=dev)  # noqa: E731
+        self.ws = dict(xn=z(16 * self.H), attn=z(16 * self.q_dim), act=z(16 * self.I), h=z(16, self.H),
+                       q=z(self.n_q, 16, 128), part=z(npart, dt=torch.float32),
+                       attn_ws=ops.attn_ws(self.n_q, max_splits, dev), argmax_ws=ops.argmax_ws(dev),
+                       post=torch.zeros(16, dtype=torch.int64, device=dev))
+        self._rope = None
+        self._taps = {}
+        torch.cuda.synchronize(dev)
+
+    # ---- HF-compatible surface (the reference loop can still drive the wrapped model)
+    @property
+    def device(self):
+        return self._dev
+
+    def __call__(self, *a, **kw):
+        return self.hf(*a, **kw)
+
+    def share_lm_head(self, packed: torch.Tensor) -> None:
+        self.lm_wp = packed
+
+    def new_cache(self, max_rows: Optional[int] = None) -> TargetKVCache:
+        if max_rows is None:
+            raise ValueError("NativeTarget.new_cache needs max_rows (prompt + new tokens + block)")
+        return TargetKVCache(self.L, self.n_kv, max_rows, self._dev)
+
+    def _rope_tab(self, need: int):
+        if self._rope is None or self._rope[0].shape[0] < need:
+            n = 1 << (max(need, 4096) - 1).bit_length()
+            self._rope = _rope_tables(128, self.theta, n, self._dev)
+        return self._rope
+
+    # ---- prefill through the wrapped model, K/V copied into the preallocated cache
+    @torch.inference_mode()
+    def prefill(self, input_ids: torch.Tensor, cache: TargetKVCache, output_hidden_states: bool = True):
+        from transformers import DynamicCache
+        P = input_ids.shape[1]
+        if P > cache.max_rows:
+            raise ValueError("target KV cache too small for the prompt")
+        tmp = DynamicCache()
+        pos = torch.arange(P, device=self._dev).unsqueeze(0)
+        out = self.hf(input_ids, position_ids=pos, past_key_values=tmp, use_cache=True, logits_to_keep=1,
+                      output_hidden_states=output_hidden_states)
+        for i in range(self.L):
+            cache.k[i, :, :P].copy_(tmp.layers[i].keys[0])
+            cache.v[i, :, :P].copy_(tmp.layers[i].values[0])
+        cache.length = P
+        return out
+
+    # ---- the verify forward on the kernels
+    @torch.inference_mode()
+    def verify(self, block_ids: torch.Tensor, start: int, cache: TargetKVCache, *, tap_layers: Sequence[int] = (),
+               temperature: float = 0.0, logits_out: Optional[torch.Tensor] = None):
+        """block_ids int64 [bs] at positions start..start+bs-1 (cache rows alike).
+        Returns (posterior ids int64 [1, bs], taps bf16 [16, len(tap_layers)*H] or None).
+        K/V of all bs rows are written; the caller crops to what it accepts."""
+        bs = block_ids.numel()
+        if bs < 1 or bs > 16:
+            raise ValueError("verify takes 1..16 block rows")
+        if start + bs > cache.max_rows:
+            raise ValueError("target KV cache too small")
+        ws, H = self.ws, self.H
+        if self.lm_wp is None:
+            self.lm_wp = ops.pack_weight(self.lm_head.weight.detach().to(BF16).contiguous())
+        cos, sin = self._rope_tab(start + bs + 64)
+        dyn = cache.dyn
+        ops.set_dyn(dyn, start, 0, bs, start)
+        taps = None
+        tap_layers = list(tap_layers)
+        if tap_layers:
+            if max(tap_layers) >= self.L - 1:
+                raise NotImplementedError("tapping the last layer (post-norm state) is not supported")
+            key = len(tap_layers)
+            if key not in self._taps:
+                self._taps[key] = torch.zeros(16, key * H, dtype=BF16, device=self._dev)
+            taps = self._taps[key]
+        ld2 = len(tap_layers) * H
+        Ls = self.layers
+        ops.norm_pack(norm_w=Ls[0]["ln1"], frag=ws["xn"], H=H, eps=self.eps, embed=self.embed, ids=block_ids,
+                      h_out=ws["h"], dyn=dyn, dyn_word=ops.DYN_BS)
+        for i, lw in enumerate(Ls):
+            ops.gemm_f32(lw["qkv"], ws["xn"], None, 1, self.nqkv, H, self.ks_qkv, ws["part"])
+            ops.qknorm_rope_append(qkv=ws["part"], nsplit=self.ks_qkv, split_stride=16 * self.nqkv, ld=self.nqkv,
+                                   q_col=0, k_col=self.q_dim, v_col=self.q_dim + self.kv_dim, ctx_row0=0, blk_row0=0,
+                                   n_q=self.n_q, n_kv=self.n_kv, q_norm_w=lw["q_norm"], k_norm_w=lw["k_norm"],
+                                   eps=self.eps, cos_tab=cos, sin_tab=sin, q_out=ws["q"], kcache=cache.k[i],
+                                   vcache=cache.v[i], dyn=dyn)
+            ops.block_attn(q=ws["q"], kcache=cache.k[i], vcache=cache.v[i], n_q=self.n_q, n_kv=self.n_kv,
+                           scale=128 ** -0.5, dyn=dyn, kv_len_max=start + bs, ws=ws["attn_ws"],
+                           max_splits=self.max_splits, out_frag=ws["attn"], causal=True)
+            ops.gemm_f32(lw["o"], ws["attn"], None, 1, H, self.q_dim, self.ks_o, ws["part"])
+            ops.norm_pack(norm_w=lw["ln2"], frag=ws["xn"], H=H, eps=self.eps, part=ws["part"], nsplit=self.ks_o,
+                          part_split=16 * H, ldp=H, resid_in=ws["h"], h_out=ws["h"], dyn=dyn, dyn_word=ops.DYN_BS)
+            ops.gemm_silu_mul(lw["gu"], ws["xn"], self.I, H, ws["act"])
+            ops.gemm_f32(lw["down"], ws["act"], None, 1, H, self.I, self.ks_down, ws["part"])
+            nxt = Ls[i + 1]["ln1"] if i + 1 < self.L else self.norm
+            h2 = None
+            if i in tap_layers:
+                j = tap_layers.index(i)
+                h2 = taps[:, j * H:(j + 1) * H]
+            ops.norm_pack(norm_w=nxt, frag=ws["xn"], H=H, eps=self.eps, part=ws["part"], nsplit=self.ks_down,
+                          part_split=16 * H, ldp=H, resid_in=ws["h"], h_out=ws["h"], h_out2=h2, ld2=ld2, dyn=dyn,
+                          dyn_word=ops.DYN_BS)
+        post = ws["post"]
+        if temperature < 1e-5:
+            ops.gemm_argmax(self.lm_wp, ws["xn"], self.V, H, 0, bs, ws["argmax_ws"], post, 0, logits=logits_out)
+            posterior = post[:bs].unsqueeze(0)
+        else:
+            logits = torch.empty(16, self.V, dtype=BF16, device=self._dev)
+            ops.gemm_argmax(self.lm_wp, ws["xn"], self.V, H, 0, bs, ws["argmax_ws"], post, 0, logits=logits)
+            posterior = sample(logits[:bs].unsqueeze(0), temperature)
+        cache.length = start + bs
+        return posterior, taps

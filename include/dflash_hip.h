@@ -105,13 +105,14 @@ int dfl_gemm_argmax(const void *wp, const void *xf, int V, int K, int row0, int 
  *   v   = part ? bf16(sum_c part[c][row_off+m][:]) : (none)
  *   h   = embed ? embed[ids[m]] : resid_in ? resid_in[m] : 0       (bf16)
  *   h   = part ? (resid_in||embed ? bf16(h + v) : v) : h            (model/dflash.py:140,144)
- *   h_out[m] = h                                   (if h_out)
+ *   h_out[m] = h                                   (if h_out; h_out2[m*ld2 ..] gets the same row:
+ *                                                   a tapped target layer, model/utils.py:16-25)
  *   frag[m]  = norm_w * bf16(h * rsqrt(mean(h^2)+eps))  (Qwen3RMSNorm, tf:...:59-64)
  * rows m >= n_valid (dyn[dyn_word], or 16) get zero fragments.  H%8==0, H<=16384.
  * part row stride ldp floats, split stride part_split floats. */
 int dfl_norm_pack(const float *part, int nsplit, int64_t part_split, int ldp, int row_off, const void *resid_in,
-                  const void *embed, const int64_t *ids, void *h_out, const void *norm_w, float eps, void *frag,
-                  int H, const int32_t *dyn, int dyn_word, void *stream);
+                  const void *embed, const int64_t *ids, void *h_out, void *h_out2, int64_t ld2, const void *norm_w,
+                  float eps, void *frag, int H, const int32_t *dyn, int dyn_word, void *stream);
 
 /* q_norm/k_norm + RoPE + KV append (model/dflash.py:71-85 with the local
  * apply_rotary_pos_emb of :22-28).  qkv: fp32 partials from dfl_gemm_f32,
@@ -123,7 +124,8 @@ int dfl_norm_pack(const float *part, int nsplit, int64_t part_split, int ldp, in
  *   kcache/vcache bf16 [n_kv][cache_rows][128] at rows S + rel, rel = row_base + i
  *   for context row i, tau + j for block row j; RoPE position = pos0 + rel.
  * cos/sin: bf16 [max_pos][64] tables (tf:...:125-137, computed by the host in fp32
- * then cast, as the reference does).  head_dim must be 128.
+ * then cast, as the reference does).  head_dim must be 128.  q_norm_w == k_norm_w ==
+ * NULL skips the per-head norms (Llama-style attention).
  * ctx_rows_override >= 0: that many context rows instead of dyn tau and no block
  * rows — the draft-cache prefill of the prompt's context in 16-row groups, with
  * row_base = index of the group's first row. */
@@ -133,15 +135,16 @@ int dfl_qknorm_rope_append(const float *qkv, int nsplit, int64_t split_stride, i
                            void *q_out, void *kcache, void *vcache, int cache_rows, const int32_t *dyn,
                            int ctx_rows_override, int row_base, void *stream);
 
-/* Bidirectional (mask-free, is_causal=False) GQA attention of the block's 16 query
- * rows over the cached prefix + this cycle's rows: softmax(q k^T * scale) v over
- * kv_len = S + tau + bs keys (model/dflash.py:86-99).  MFMA QK^T / PV, K/V tiles
+/* GQA attention of the block's 16 query rows over the cached prefix + this cycle's
+ * rows: softmax(q k^T * scale) v over kv_len = S + tau + bs keys.  causal = 0: no mask
+ * (the draft, is_causal=False, model/dflash.py:86-99).  causal = 1: query row j sees
+ * cache rows <= S + tau + j (the target's verify forward over the same block).  MFMA QK^T / PV, K/V tiles
  * staged in LDS, split over the key axis with a log-sum-exp merge.
  * ws: dfl_attn_ws_bytes(n_q, max_splits) bytes.  out: frag16 [n_q*128/8][16][8]. */
 int64_t dfl_attn_ws_bytes(int n_q, int max_splits);
 int dfl_block_attn(const void *q, const void *kcache, const void *vcache, int cache_rows, int n_q, int n_kv,
-                   float scale, const int32_t *dyn, int kv_len_max, void *ws, int max_splits, void *out_frag,
-                   void *stream);
+                   float scale, int causal, const int32_t *dyn, int kv_len_max, void *ws, int max_splits,
+                   void *out_frag, void *stream);
 
 /* First-max-index argmax over the last axis (model/utils.py:28-29).
  * dtype: 0 = bf16, 1 = fp32.  ids int64 [rows]. */

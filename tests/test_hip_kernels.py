@@ -256,6 +256,58 @@ def test_block_attn(ops, n_q, n_kv, S, tau, bs):
     assert torch.isfinite(got).all()
 
 
+@pytest.mark.parametrize("n_q,n_kv,S,bs", [(4, 2, 0, 16), (32, 8, 1024, 16), (8, 2, 131, 12), (32, 8, 3, 5)])
+def test_block_attn_causal(ops, n_q, n_kv, S, bs):
+    """Target-verify form: query row j sees cache rows <= S + j."""
+    g = gen(S + n_q + 1)
+    kv_len = S + bs
+    q = torch.randn(n_q, 16, 128, generator=g).to(BF16)
+    k = torch.randn(n_kv, kv_len + 8, 128, generator=g).to(BF16)
+    v = torch.randn(n_kv, kv_len + 8, 128, generator=g).to(BF16)
+    dyn = torch.zeros(8, dtype=torch.int32, device=dev())
+    ops.set_dyn(dyn, S, 0, bs, S)
+    out = torch.empty(16 * n_q * 128, dtype=BF16, device=dev())
+    ops.block_attn(q=q.to(dev()), kcache=k.to(dev()), vcache=v.to(dev()), n_q=n_q, n_kv=n_kv, scale=128 ** -0.5,
+                   dyn=dyn, kv_len_max=kv_len, ws=ops.attn_ws(n_q, 32, dev()), max_splits=32, out_frag=out,
+                   causal=True)
+    got = unfrag(out, n_q * 128).cpu().float().view(16, n_q, 128)[:bs]
+    G = n_q // n_kv
+    kk = k[:, :kv_len].float().repeat_interleave(G, dim=0)
+    vv = v[:, :kv_len].float().repeat_interleave(G, dim=0)
+    sc = torch.einsum("hqd,hkd->hqk", q[:, :bs].float(), kk) * 128 ** -0.5
+    mask = torch.arange(kv_len)[None, :] > (S + torch.arange(bs))[:, None]
+    sc = sc.masked_fill(mask[None], float("-inf"))
+    ref = torch.einsum("hqk,hkd->qhd", torch.softmax(sc, dim=-1), vv)
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max() <= 2 ** -6 * ref.abs().max()
+
+
+def test_qknorm_rope_without_norm(ops):
+    """Llama-style attention: no per-head q/k norm, RoPE only."""
+    from oracle import dflash_oracle as O
+    from dflash_amd.model import _rope_tables
+    n_q, n_kv, S, bs = 4, 2, 9, 7
+    ld = (n_q + 2 * n_kv) * 128
+    part = torch.randn(1, 16, ld, generator=gen(3))
+    cos, sin = _rope_tables(128, 5e5, 128, dev())
+    dyn = torch.zeros(8, dtype=torch.int32, device=dev())
+    ops.set_dyn(dyn, S, 0, bs, S)
+    kc = torch.zeros(n_kv, 64, 128, dtype=BF16, device=dev())
+    vc = torch.zeros_like(kc)
+    q_out = torch.zeros(n_q, 16, 128, dtype=BF16, device=dev())
+    ops.qknorm_rope_append(qkv=part.to(dev()), nsplit=1, split_stride=16 * ld, ld=ld, q_col=0, k_col=n_q * 128,
+                           v_col=(n_q + n_kv) * 128, ctx_row0=0, blk_row0=0, n_q=n_q, n_kv=n_kv, q_norm_w=None,
+                           k_norm_w=None, eps=1e-6, cos_tab=cos, sin_tab=sin, q_out=q_out, kcache=kc, vcache=vc,
+                           dyn=dyn)
+    lin = part[0].to(BF16)[:bs]
+    q = lin[:, :n_q * 128].view(1, bs, n_q, 128).transpose(1, 2)
+    k = lin[:, n_q * 128:(n_q + n_kv) * 128].view(1, bs, n_kv, 128).transpose(1, 2)
+    c, s = O.rope_cos_sin(torch.arange(S, S + bs)[None], O.rope_inv_freq(128, 5e5), BF16)
+    qr, kr = O.apply_rotary_std(q, k, c, s)
+    assert torch.equal(q_out[:, :bs].cpu(), qr[0])
+    assert torch.equal(kc[:, S:S + bs].cpu(), kr[0])
+
+
 # ------------------------------------------------------------------ integer side, golden
 def test_argmax_golden(ops):
     z = np.load(os.path.join(H.GOLDEN, "argmax.npz"))

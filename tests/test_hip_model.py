@@ -209,3 +209,102 @@ def test_draft_tokens_match_oracle_tiny():
         ref_ids = ref_logits.argmax(-1)
         assert torch.equal(blk[0, 1:].cpu()[safe], ref_ids[safe])
         assert (blk[0, 1:].cpu() == ref_ids).float().mean() >= 0.8
+
+
+# ------------------------------------------------------------------ native target verify
+def _tiny_hf(dtype=BF16, layers=6):
+    from dflash_amd.synthetic import make_hf_qwen3
+    torch.manual_seed(11)
+    return make_hf_qwen3({**H.TINY_TARGET, "num_layers": layers}, dev(), dtype=dtype)
+
+
+def test_native_verify_matches_hf_forward():
+    """Same block through the wrapped HF model and through the kernels: logits, tapped
+    hidden rows and the appended K/V agree within the bf16 tolerance of DESIGN.md §2."""
+    from transformers import DynamicCache
+    from dflash_amd import NativeTarget
+    hf = _tiny_hf()
+    nt = NativeTarget(hf)
+    g = torch.Generator().manual_seed(2)
+    prompt = torch.randint(0, 2000, (1, 45), generator=g).to(dev())
+    block = torch.randint(0, 2000, (1, 16), generator=g).to(dev())
+    taps = [1, 3]
+    cache = nt.new_cache(128)
+    out0 = nt.prefill(prompt, cache)
+    logits = torch.zeros(16, 2048, dtype=BF16, device=dev())
+    post, th = nt.verify(block[0], 45, cache, tap_layers=taps, logits_out=logits)
+    # reference: HF forward over prompt then block
+    rc = DynamicCache()
+    hf(prompt, past_key_values=rc, use_cache=True)
+    ref = hf(block, position_ids=torch.arange(45, 61, device=dev())[None], past_key_values=rc, use_cache=True,
+             output_hidden_states=True)
+    rl = ref.logits[0].float()
+    scale = rl.abs().max()
+    assert (logits.float() - rl).abs().max() <= 4e-2 * scale
+    assert torch.equal(post[0], torch.argmax(logits, dim=-1))
+    top2 = rl.topk(2, dim=-1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 8e-2 * scale
+    assert torch.equal(post[0][safe], rl.argmax(-1)[safe])
+    for j, l in enumerate(taps):
+        r = ref.hidden_states[l + 1][0].float()
+        d = (th[:, j * 512:(j + 1) * 512].float() - r).abs()
+        assert d.max() <= 4e-2 * r.abs().max() and d.mean() <= 4e-3 * r.abs().max()
+    for li in (0, 5):
+        for got, want in ((cache.k[li][:, :61], rc.layers[li].keys[0]), (cache.v[li][:, :61], rc.layers[li].values[0])):
+            d = (got.float() - want.float()).abs()
+            assert d.max() <= 6e-2 * want.float().abs().max() and d.mean() <= 4e-3 * want.float().abs().max()
+    assert cache.get_seq_length() == 61
+    assert out0.logits.shape[1] == 1
+
+
+def test_native_target_end_to_end_lossless_walk():
+    """A large-margin synthetic target (dflash_amd.synthetic.impose_greedy_walk): the
+    committed ids are its closed-form greedy walk through the native verify AND through
+    the plain HF verify, with scripted acceptance lengths reproduced exactly."""
+    from dflash_amd import NativeTarget, dflash_generate
+    from dflash_amd.synthetic import greedy_walk, impose_greedy_walk
+    cfg = H.tiny_cfg()
+    m = make_model(cfg)
+    hf = _tiny_hf()
+    perm = impose_greedy_walk(hf, seed=5)
+    prompt = torch.randint(0, 2000, (1, 33), generator=torch.Generator().manual_seed(4)).to(dev())
+    n_new = 80
+    G = greedy_walk(perm, prompt, n_new + 40).to(dev())
+    plan = H.make_plan(64, 16, 17)
+
+    def hook(blk, start, call):
+        k = plan[call]
+        blk[0, 1:k + 1] = G[start + 1:start + k + 1]
+        if k + 1 < blk.shape[1]:
+            w = G[start + k + 1]
+            blk[0, k + 1] = torch.where(blk[0, k + 1] == w, (w + 1) % 2000, blk[0, k + 1])
+
+    runs = {}
+    for name, tgt in (("hf", hf), ("native", NativeTarget(hf))):
+        r = dflash_generate(m, tgt, prompt, cfg.mask_token_id, n_new, 16, None, 0.0, draft_token_hook=hook)
+        runs[name] = r
+        assert r.output_ids[0].tolist() == G[:33 + n_new].tolist(), name
+    assert runs["hf"].acceptance_lengths == runs["native"].acceptance_lengths
+    exp = []
+    tot, c = 0, 0
+    while tot < n_new:
+        t = min(plan[c] + 1, n_new - tot)
+        exp.append(t)
+        tot += t
+        c += 1
+    assert runs["native"].acceptance_lengths == exp
+
+
+def test_temperature_path_with_sharp_logits():
+    """T = 0.7 (BASELINE config 4's sampling path): softmax + torch.multinomial on the
+    posterior, acceptance on the device.  With the scripted target's +-10 logits the
+    draw is deterministic, so the ids equal the T = 0 golden run."""
+    cfg = H.tiny_cfg()
+    m = make_model(cfg)
+    g = E2E["bf16_sdpa/spec"]
+    tgt = _scripted(g, cfg)
+    torch.manual_seed(0)
+    ids = m.spec_generate(target=tgt, input_ids=torch.tensor([g["prompt"]], device=dev()),
+                          max_new_tokens=g["max_new_tokens"], stop_token_ids=None, temperature=0.7,
+                          draft_token_hook=tgt.draft_token_hook)
+    assert ids[0].tolist() == g["ids"]
