@@ -277,9 +277,14 @@ extern "C" int dfl_pack_weight_gateup(const void *gate, const void *up, void *wp
   return DFL_OK;
 }
 
-static int grid_x_for(int ngroups) {
-  // one 16-wave workgroup per CU; fewer when there are fewer tile groups
-  return ngroups < 256 ? ngroups : 256;
+// Workgroups along x for `ngroups` tile groups when the K axis is cut `ksplit` ways: at
+// most 256 workgroups in all (one 16-wave workgroup per CU), every workgroup walking
+// the same number of groups so that no CU streams twice as long as its neighbour.
+static int grid_x_for(int ngroups, int ksplit = 1) {
+  int gx_max = 256 / ksplit;
+  if (gx_max < 1) gx_max = 1;
+  const int per_wg = (ngroups + gx_max - 1) / gx_max;
+  return (ngroups + per_wg - 1) / per_wg;
 }
 
 extern "C" int dfl_gemm_f32(const void *wp, const void *xf0, const void *xf1, int mt, int N, int K, int ksplit,
@@ -300,7 +305,7 @@ extern "C" int dfl_gemm_f32(const void *wp, const void *xf0, const void *xf1, in
   a.nfr = (KS + 16 * ksplit - 1) / (16 * ksplit);
   a.out = out;
   a.ldo = N;
-  dim3 grid(grid_x_for(a.ntiles), ksplit);
+  dim3 grid(grid_x_for(a.ntiles, ksplit), ksplit);
   if (mt == 1)
     hipLaunchKernelGGL((k_gemm<1, 8, EPI_F32>), grid, dim3(1024), 0, (hipStream_t)stream, a);
   else

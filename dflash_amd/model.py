@@ -141,11 +141,11 @@ class DFlashDraftModel:
             c, d = self.config, self.device
             H, I = c.hidden_size, c.intermediate_size
             nqkv = c.q_dim + 2 * c.kv_dim
-            self.ks_fc = ops.min_ksplit(c.fc_in, 1)
-            self.ks_qkv = ops.min_ksplit(H, 2)
-            self.ks_o = ops.min_ksplit(c.q_dim, 1)
-            self.ks_down = ops.min_ksplit(I, 1)
-            self.ks_kv = ops.min_ksplit(H, 1)
+            self.ks_fc = ops.pick_ksplit(H, c.fc_in, 1)
+            self.ks_qkv = ops.pick_ksplit(nqkv, H, 2)
+            self.ks_o = ops.pick_ksplit(H, c.q_dim, 1)
+            self.ks_down = ops.pick_ksplit(H, I, 1)
+            self.ks_kv = ops.pick_ksplit(2 * c.kv_dim, H, 1)
             npart = max(self.ks_fc * 16 * H, self.ks_qkv * 32 * nqkv, self.ks_o * 16 * H, self.ks_down * 16 * H,
                         self.ks_kv * 16 * 2 * c.kv_dim)
             self.max_splits = 32

@@ -74,6 +74,27 @@ def min_ksplit(K: int, mt: int) -> int:
     return (K + per - 1) // per
 
 
+def pick_ksplit(N: int, K: int, mt: int) -> int:
+    """K split for dfl_gemm_f32 that fills the 256 CUs evenly: work units = column tiles x
+    K chunks, dealt to <= 256 workgroups of equal load, preferring >= 2 tiles per workgroup
+    (the next tile's weights are prefetched under the current one).  Measured on MI355X
+    (scripts/bench_gemm.py): every shape runs ~3.6 us + bytes / 6.5 TB/s for any split
+    near this choice, so the picker only has to avoid the unbalanced ones."""
+    ntiles, ks_steps = N // 16, K // 32
+    best, best_score = None, None
+    for ks in range(min_ksplit(K, mt), 17):
+        nfr = -(-ks_steps // (16 * ks))
+        if nfr < 2 and ks > min_ksplit(K, mt):
+            break
+        gx_max = max(1, 256 // ks)
+        per_wg = -(-ntiles // gx_max)
+        fill = (ntiles * ks) / (256.0 * per_wg)           # busy fraction of the chip over the launch
+        score = (round(min(fill, 1.0), 3), min(per_wg, 2), -ks)
+        if best_score is None or score > best_score:
+            best, best_score = ks, score
+    return best
+
+
 def gemm_silu_mul(wp_gu, xf, I: int, K: int, act_frag: torch.Tensor) -> None:
     assert act_frag.numel() >= 16 * I
     check(lib().dfl_gemm_silu_mul(_p(wp_gu, BF16, "wp_gu"), _p(xf, BF16, "xf"), I, K, _p(act_frag, BF16, "act"),

@@ -106,9 +106,9 @@ class NativeTarget:
         self.max_splits = max_splits
         self.q_dim, self.kv_dim = self.n_q * 128, self.n_kv * 128
         self.nqkv = self.q_dim + 2 * self.kv_dim
-        self.ks_qkv = ops.min_ksplit(self.H, 1)
-        self.ks_o = ops.min_ksplit(self.q_dim, 1)
-        self.ks_down = ops.min_ksplit(self.I, 1)
+        self.ks_qkv = ops.pick_ksplit(self.nqkv, self.H, 1)
+        self.ks_o = ops.pick_ksplit(self.H, self.q_dim, 1)
+        self.ks_down = ops.pick_ksplit(self.H, self.I, 1)
         npart = max(self.ks_qkv * 16 * self.nqkv, self.ks_o * 16 * self.H, self.ks_down * 16 * self.H)
         z = lambda *s, dt=BF16: torch.zeros(*s, dtype=dt, device=dev)  # noqa: E731
         self.ws = dict(xn=z(16 * self.H), attn=z(16 * self.q_dim), act=z(16 * self.I), h=z(16, self.H),

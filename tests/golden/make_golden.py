@@ -16,6 +16,7 @@ Fixtures (SURVEY.md §8c list):
   G4 e2e_<name>.json           spec_generate / dflash_generate / _policy ids
   G5 scheduler.json            EWMAPerformanceScheduler decision traces
   G6 sample_t.npz              sample(logits, 0.7) under torch.manual_seed
+  G7 harness.json              summarize_mode / summarize_profile of benchmark.py
 """
 import json
 import os
@@ -288,6 +289,29 @@ def gen_sample_t():
     print("G6 done")
 
 
+# ---------------------------------------------------------------- G7
+def gen_harness():
+    """summarize_mode / summarize_profile of the reference harness on synthetic samples."""
+    g = np.random.default_rng(3)
+    samples = []
+    for i in range(5):
+        n_out = int(g.integers(50, 300))
+        dec = float(g.uniform(0.5, 3.0))
+        samples.append(dict(num_input_tokens=int(g.integers(10, 80)), num_output_tokens=n_out,
+                            time_to_first_token=float(g.uniform(0.05, 0.2)), time_per_output_token=dec / n_out,
+                            wall_time_s=dec + 0.3, acceptance_lengths=[int(x) for x in g.integers(1, 17, size=12)],
+                            profile_summary={"target_prefill_s": float(g.uniform(0.05, 0.2)),
+                                             "target_decode_s": float(g.uniform(0.5, 2.0)),
+                                             "draft_decode_s": float(g.uniform(0.05, 0.4)),
+                                             "cycle_decode_s_sum": float(g.uniform(0.6, 2.5)),
+                                             "decode_wall_s": dec, "profiled_cycles": 12}))
+    ns = [types.SimpleNamespace(**s) for s in samples]
+    json.dump({"samples": samples, "summarize_mode": ref_bench.summarize_mode(ns),
+               "summarize_profile": ref_bench.summarize_profile(ns)},
+              open(os.path.join(HERE, "harness.json"), "w"))
+    print("G7 done")
+
+
 if __name__ == "__main__":
     tiny, mid = H.tiny_cfg(), H.mid_cfg()
     # (bs, tau_next): block size this cycle, tokens committed after it (= next cycle's ctx rows)
@@ -301,3 +325,4 @@ if __name__ == "__main__":
     gen_e2e()
     gen_scheduler()
     gen_sample_t()
+    gen_harness()

@@ -1,0 +1,56 @@
+"""Harness wire format: numbers equal the reference's summarize_* (golden G7) and every
+line run_block_sweep.sh greps for is present in the form its regexes expect."""
+import json
+import os
+import re
+from types import SimpleNamespace
+
+import helpers as H
+from dflash_amd import harness
+
+G = json.load(open(os.path.join(H.GOLDEN, "harness.json")))
+NS = [SimpleNamespace(**s) for s in G["samples"]]
+
+# run_block_sweep.sh:199-212
+SWEEP_PATTERNS = [r"Decoding speedup: [0-9.]+$", r"Average Acceptance length: [0-9.]+$",
+                  r"Speculative total_wall_s: [0-9.]+$", r"Speculative tokens_per_sec: [0-9.]+$",
+                  r"Speculative TPOT: [0-9.]+$", r"Speculative TTFT: [0-9.]+$", r"^Hardware GPU:", r"^Hardware CUDA:",
+                  r"^Hardware Torch:", r"Baseline total_wall_s: [0-9.]+$", r"Baseline tokens_per_sec: [0-9.]+$",
+                  r"Baseline TPOT: [0-9.]+$", r"Baseline TTFT: [0-9.]+$", r"Acceptance length histogram:"]
+
+
+def test_summaries_equal_reference():
+    assert harness.summarize_mode(NS) == G["summarize_mode"]
+    assert harness.summarize_profile(NS) == G["summarize_profile"]
+    assert harness.summarize_profile([SimpleNamespace(profile_summary=None)]) is None
+
+
+def test_stat_lines_match_the_sweep_regexes():
+    responses = [{1: NS[i], 16: NS[(i + 1) % len(NS)]} for i in range(len(NS))]
+    lines = harness.stat_lines(responses, 16, draft_steps=1, baseline=True, collect_profile=True,
+                               gpu_name="AMD Instinct MI355X", runtime_version=None, torch_version="2.10.0+rocm7.0")
+    for pat in SWEEP_PATTERNS:
+        assert any(re.search(pat, ln) for ln in lines), pat
+    sm = G["summarize_mode"]
+    assert f"Baseline TPOT: {sm['avg_tpot_s']:.6f}" in lines          # both modes share the sample set here
+    assert "Speculative profile total_profiled_cycles: 60" in lines
+    hist = next(ln for ln in lines if ln.startswith("Acceptance length histogram:"))
+    assert hist.count("%") == 17
+    skipped = harness.stat_lines(responses, 16, baseline=False)
+    assert "Decoding speedup: N/A (baseline skipped)" in skipped and not any("Baseline" in ln for ln in skipped)
+
+
+def test_jsonl_rows(tmp_path):
+    spec = SimpleNamespace(**{**G["samples"][0], "cycle_trace": [{"cycle_idx": 0, "tau": 3}]})
+    row = harness.output_record(rank=0, dataset_row_idx=4, turn_index=0, dataset="synthetic", prompt_text="p",
+                                input_text="i", block_size=16, draft_steps=1, speculative=spec, speculative_text="o")
+    assert list(row) == ["rank", "dataset_row_idx", "turn_index", "dataset", "prompt_text", "input_text",
+                         "block_size", "draft_steps", "baseline", "speculative"]
+    assert list(row["speculative"]) == ["output_text", "num_input_tokens", "num_output_tokens", "wall_time_s",
+                                        "ttft_s", "tpot_s", "acceptance_lengths", "profile_summary"]
+    tr = list(harness.cycle_trace_records(spec, rank=0, dataset="synthetic", dataset_row_idx=4, turn_index=0,
+                                          mode="speculative", block_size=16))
+    assert tr == [{"rank": 0, "dataset": "synthetic", "dataset_row_idx": 4, "turn_index": 0, "mode": "speculative",
+                   "block_size": 16, "cycle_idx": 0, "tau": 3}]
+    harness.write_jsonl(tmp_path / "o" / "out.jsonl", [row])
+    assert json.loads(open(tmp_path / "o" / "out.jsonl").read()) == row

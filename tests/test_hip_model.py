@@ -308,3 +308,29 @@ def test_temperature_path_with_sharp_logits():
                           max_new_tokens=g["max_new_tokens"], stop_token_ids=None, temperature=0.7,
                           draft_token_hook=tgt.draft_token_hook)
     assert ids[0].tolist() == g["ids"]
+
+
+def test_from_pretrained_checkpoint_dir(tmp_path):
+    """HF checkpoint directory (config.json with block_size /
+    num_target_layers / dflash_config + sharded *.safetensors with the reference's key
+    names) loads into the same packed weights as load_state_dict."""
+    from safetensors.torch import save_file
+    from dflash_amd import DFlashDraftModel
+    cfg = H.tiny_cfg()
+    sd = H.draft_weights(cfg, dtype=BF16)
+    keys = sorted(sd)
+    save_file({k: sd[k] for k in keys[:len(keys) // 2]}, str(tmp_path / "model-00001-of-00002.safetensors"))
+    save_file({k: sd[k] for k in keys[len(keys) // 2:]}, str(tmp_path / "model-00002-of-00002.safetensors"))
+    hf_cfg = {"architectures": ["DFlashDraftModel"], "hidden_size": 512, "num_hidden_layers": 2,
+              "num_attention_heads": 4, "num_key_value_heads": 2, "head_dim": 128, "intermediate_size": 1024,
+              "vocab_size": 2048, "rms_norm_eps": 1e-6, "rope_theta": 1000000.0, "max_position_embeddings": 40960,
+              "attention_bias": False, "block_size": 16, "num_target_layers": 6, "torch_dtype": "bfloat16",
+              "dflash_config": {"mask_token_id": 2047, "target_layer_ids": [1, 3]}}
+    (tmp_path / "config.json").write_text(json.dumps(hf_cfg))
+    a = DFlashDraftModel.from_pretrained(str(tmp_path), device=dev())
+    b = make_model(cfg)
+    assert (a.block_size, a.mask_token_id, a.target_layer_ids) == (16, 2047, [1, 3])
+    assert torch.equal(a.w["fc"], b.w["fc"])
+    for la, lb in zip(a.w["layers"], b.w["layers"]):
+        for k in la:
+            assert torch.equal(la[k], lb[k]), k
