@@ -29,6 +29,9 @@ SIGNATURES = {
                                     _i, _i, _p]),
     "dfl_attn_ws_bytes": (_i64, [_i, _i]),
     "dfl_block_attn": (_i, [_p, _p, _p, _i, _i, _i, _f, _i, _p, _i, _p, _i, _p, _p]),
+    "dfl_attn_fused_ws_bytes": (_i64, [_i, _i, _i]),
+    "dfl_attn_fused": (_i, [_p, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _f, _p, _p, _i, _p, _p, _i, _f, _i, _p,
+                            _i, _p, _i, _p, _p]),
     "dfl_argmax": (_i, [_p, _i, _i, _i64, _p, _p]),
     "dfl_accept_commit": (_i, [_p, _p, _i, _p, _i64, _p, _p, _i, _p, _p]),
 }

@@ -158,33 +158,82 @@ __global__ __launch_bounds__(512) void k_block_attn(AttnArgs a) {
   }
 }
 
+// Merge the key splits of NH (head, q, 8-column group) items that differ only in the
+// head (consecutive heads): branch-free, and every load of a split pair is issued before
+// any is used (an empty split has m = -inf, l = 0 and gets weight 0).  Fixed split order,
+// so the sums are reproducible.
+template <int NH>
+__device__ __forceinline__ void merge_items(const float *o_part, const float *ml_part, int nsplit, int n_q, int hh0,
+                                            int q, int dg, bf16x8 (&out)[NH]) {
+  const int64_t sml = (int64_t)n_q * 16 * 2, so = (int64_t)n_q * 16 * 128;
+  const float *ml0 = ml_part + ((int64_t)hh0 * 16 + q) * 2;
+  const float *o0 = o_part + ((int64_t)hh0 * 16 + q) * 128 + dg * 8;
+  float M[NH];
+#pragma unroll
+  for (int h = 0; h < NH; ++h) M[h] = -INFINITY;
+  for (int s = 0; s < nsplit; s += 4) {
+    float mv[4][NH];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int sc = s + u < nsplit ? s + u : nsplit - 1;
+#pragma unroll
+      for (int h = 0; h < NH; ++h) mv[u][h] = ml0[sc * sml + h * 32];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int h = 0; h < NH; ++h) M[h] = fmaxf(M[h], mv[u][h]);
+  }
+  float acc[NH][8], L[NH];
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+    M[h] = M[h] == -INFINITY ? 0.f : M[h];
+    L[h] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[h][j] = 0.f;
+  }
+  for (int s = 0; s < nsplit; s += 2) {
+    float ms[2][NH], ls[2][NH];
+    f32x4 a0[2][NH], a1[2][NH];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int sc = s + u < nsplit ? s + u : nsplit - 1;
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        ms[u][h] = ml0[sc * sml + h * 32];
+        ls[u][h] = ml0[sc * sml + h * 32 + 1];
+        a0[u][h] = *reinterpret_cast<const f32x4 *>(o0 + sc * so + h * 2048);
+        a1[u][h] = *reinterpret_cast<const f32x4 *>(o0 + sc * so + h * 2048 + 4);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        const float wgt = s + u < nsplit ? exp2f(ms[u][h] - M[h]) : 0.f;  // exp2(-inf) = 0: empty split
+        L[h] += wgt * ls[u][h];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[h][j] += wgt * a0[u][h][j];
+          acc[h][4 + j] += wgt * a1[u][h][j];
+        }
+      }
+  }
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+    const float inv = L[h] > 0.f ? 1.f / L[h] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[h][j] = f2bf(acc[h][j] * inv);
+  }
+}
+
 // grid = n_q heads, 256 threads: thread (q = tid>>4, dg = tid&15) owns 8 d values
 __global__ __launch_bounds__(256) void k_attn_merge(const float *o_part, const float *ml_part, int nsplit, int n_q,
                                                     bf16x8 *out_frag) {
   const int head = blockIdx.x, q = threadIdx.x >> 4, dg = threadIdx.x & 15;
-  float M = -INFINITY;
-  for (int s = 0; s < nsplit; ++s) M = fmaxf(M, ml_part[(((int64_t)s * n_q + head) * 16 + q) * 2]);
-  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  float L = 0.f;
-  for (int s = 0; s < nsplit; ++s) {
-    const float *ml = ml_part + (((int64_t)s * n_q + head) * 16 + q) * 2;
-    if (ml[1] <= 0.f) continue;  // empty split
-    const float wgt = exp2f(ml[0] - M);
-    L += wgt * ml[1];
-    const float *op = o_part + (((int64_t)s * n_q + head) * 16 + q) * 128 + dg * 8;
-    const f32x4 a0 = *reinterpret_cast<const f32x4 *>(op);
-    const f32x4 a1 = *reinterpret_cast<const f32x4 *>(op + 4);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      acc[j] += wgt * a0[j];
-      acc[4 + j] += wgt * a1[j];
-    }
-  }
-  const float inv = L > 0.f ? 1.f / L : 0.f;
-  bf16x8 o;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) o[j] = f2bf(acc[j] * inv);
-  out_frag[(head * 16 + dg) * 16 + q] = o;  // frag16 chunk (n>>3 = head*16+dg, row q)
+  bf16x8 r[1];
+  merge_items<1>(o_part, ml_part, nsplit, n_q, head, q, dg, r);
+  out_frag[(head * 16 + dg) * 16 + q] = r[0];  // frag16 chunk (n>>3 = head*16+dg, row q)
 }
 
 }  // namespace
@@ -222,5 +271,464 @@ extern "C" int dfl_block_attn(const void *q, const void *kcache, const void *vca
   hipLaunchKernelGGL(k_attn_merge, dim3(n_q), dim3(256), 0, (hipStream_t)stream, (const float *)a.o_part,
                      (const float *)a.ml_part, nsplit, n_q, (bf16x8 *)out_frag);
   DFL_CHECK_LAUNCH("dfl_block_attn");
+  return DFL_OK;
+}
+
+// ============================================================================
+// Fused attention stage: one launch does what k_qknorm_rope + k_block_attn +
+// k_attn_merge do in three (the stage is launch/latency-bound: ~5+9+9 us per layer in
+// profiles/r1_cycle_breakdown.txt against ~1 us of actual data movement).
+//   grid = (kv heads, key splits), workgroup = G waves (wave g = query head kvh*G+g).
+//   phase 0  every workgroup turns its heads' q rows from the QKV GEMM's fp32 partials
+//            into bf16 q (Linear rounding, per-head RMSNorm, RoPE) in LDS — all 16 rows
+//            of a head in flight at once (unconditional loads, DPP reductions);
+//   phase 1  the LAST split does the same for the new K rows and copies the new V rows
+//            (tau + bs <= 32 rows of its kv head) into the cache for later cycles AND
+//            into LDS, from where its tiles take them.  Split ranges are laid out so
+//            that every row >= S belongs to the last split: no other workgroup reads a
+//            cache row written in this launch;
+//   phase 2  the tile loop of k_block_attn with K/V chunks prefetched two tiles ahead,
+//            the first two requested before the prologues;
+//   phase 3  (m, l, O) partials; the last workgroup to arrive for a kv head (agent-scope
+//            release -> ticket -> acquire, cdna guide §6 G16) merges the splits in a
+//            fixed order and writes frag16.  One split: written directly.
+namespace {
+
+struct FusedAttnArgs {
+  const float *qkv;
+  int nsplit_k;
+  int64_t split_stride;
+  int ld, q_col, k_col, v_col, ctx_row0, blk_row0;
+  const bf16_t *q_w, *k_w;
+  float eps;
+  const bf16_t *cos_tab, *sin_tab;
+  int max_pos;
+  bf16_t *kc, *vc;
+  int cache_rows;
+  int n_q, n_kv, G;
+  float scale_log2;
+  int causal;
+  const int32_t *dyn;
+  bf16x8 *out_frag;
+  float *o_part;   // [nsplit][n_q][16][128]
+  float *ml_part;  // [nsplit][n_q][16][2]
+  int *tickets;    // [n_kv], zero before the first launch; the merger leaves it zero
+};
+
+// NI (row, head) items of 128 values at once on one wave; lane owns d = l and l + 64.
+// brow[i] < 0 marks an absent item (its outputs are garbage, never stored).  rope[i]:
+// per-head norm (if nw) + RoPE; else the plain bf16-rounded copy (V rows).
+// All loads are unconditional: a runtime branch around a load makes hipcc wait vmcnt(0)
+// per element (guide §5 trap c) — measured 50 us per launch when they were guarded.
+template <int NI>
+__device__ __forceinline__ void rope_items(const FusedAttnArgs &a, const int (&brow)[NI], const int (&col)[NI],
+                                           const int (&pos)[NI], const bool (&rope)[NI], const bf16_t *nw, int l,
+                                           float (&o1)[NI], float (&o2)[NI]) {
+  float x1[NI], x2[NI], cs[NI], sn[NI];
+  const float *rp[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    x1[i] = 0.f;
+    x2[i] = 0.f;
+    rp[i] = a.qkv + (int64_t)(brow[i] < 0 ? 0 : brow[i]) * a.ld + col[i] + l;
+    int pp = pos[i] < a.max_pos ? pos[i] : a.max_pos - 1;
+    pp = pp < 0 ? 0 : pp;
+    cs[i] = bf2f(a.cos_tab[(int64_t)pp * 64 + l]);
+    sn[i] = bf2f(a.sin_tab[(int64_t)pp * 64 + l]);
+  }
+  for (int s = 0; s < a.nsplit_k; ++s) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      x1[i] += rp[i][s * a.split_stride];
+      x2[i] += rp[i][s * a.split_stride + 64];
+    }
+  }
+  const float w1 = nw ? bf2f(nw[l]) : 1.f, w2 = nw ? bf2f(nw[l + 64]) : 1.f;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    x1[i] = rbf(x1[i]);  // the Linear's bf16 output
+    x2[i] = rbf(x2[i]);
+    float n1 = x1[i], n2 = x2[i];
+    if (nw) {
+      const float ss = wave_sum(x1[i] * x1[i] + x2[i] * x2[i]);
+      const float rstd = rsqrtf(ss * (1.f / 128.f) + a.eps);
+      n1 = rbf(w1 * rbf(x1[i] * rstd));
+      n2 = rbf(w2 * rbf(x2[i] * rstd));
+    }
+    const float r1 = rbf(rbf(n1 * cs[i]) + rbf(-n2 * sn[i]));
+    const float r2 = rbf(rbf(n2 * cs[i]) + rbf(n1 * sn[i]));
+    o1[i] = rope[i] ? r1 : x1[i];
+    o2[i] = rope[i] ? r2 : x2[i];
+  }
+}
+
+#ifdef DFL_ATTN_STAMPS  // diagnostic build only (scripts/dbg_attn_stamps.py): 100 MHz wall stamps per phase
+__device__ unsigned long long g_stamps[2][8];
+#define STAMP(i)                                                                           \
+  do {                                                                                     \
+    if (tid == 0 && kvh == 0 && (split == 0 || split == nsplit - 1))                       \
+      g_stamps[split == 0 ? 0 : 1][i] = __builtin_amdgcn_s_memrealtime();                 \
+  } while (0)
+#else
+#define STAMP(i)
+#endif
+
+template <int G>
+__global__ __launch_bounds__(G * 64) void k_attn_fused(FusedAttnArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds_k[32 * 256];
+  __shared__ __attribute__((aligned(16))) char lds_v[32 * 256];
+  __shared__ __attribute__((aligned(16))) bf16_t new_k[32][128];
+  __shared__ __attribute__((aligned(16))) bf16_t new_v[32][128];
+  __shared__ __attribute__((aligned(16))) bf16_t q_lds[G][16][128];
+  __shared__ int s_last;
+
+  constexpr int nthr = G * 64;
+  const int tid = threadIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
+  const int kvh = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
+  const int head = kvh * G + wv;
+  const int S = a.dyn[DFL_DYN_S], tau = a.dyn[DFL_DYN_TAU], bs = a.dyn[DFL_DYN_BS], pos0 = a.dyn[DFL_DYN_POS0];
+  const int qbase = S + tau;
+  const int kv_len = qbase + bs;
+  const int n_new = tau + bs;  // <= 32
+  const int ntiles = (kv_len + 31) >> 5;
+  STAMP(0);
+
+  // ---- key-tile range of this split.  The last split owns every tile that holds a row
+  // >= S (tiles >= S>>5) and an even share of the rest.
+  int t0, t1;
+  {
+    const int tnew = S >> 5;
+    const int tps = (ntiles + nsplit - 1) / nsplit;
+    int last0 = ntiles - tps;
+    last0 = last0 < 0 ? 0 : (last0 > tnew ? tnew : last0);
+    if (split == nsplit - 1) {
+      t0 = last0;
+      t1 = ntiles;
+    } else {
+      const int per = (last0 + nsplit - 2) / (nsplit - 1);
+      t0 = split * per;
+      t1 = t0 + per;
+      t0 = t0 > last0 ? last0 : t0;
+      t1 = t1 > last0 ? last0 : t1;
+    }
+  }
+  const bool is_last_split = split == nsplit - 1;
+
+  // K/V chunk ownership: chunk c of a tile = (row c>>4, 16-B piece c&15); a thread owns
+  // chunks tid, tid+nthr, ...  Old rows come from the cache; rows >= S (last split only)
+  // are replaced from new_k / new_v when the tile is staged.  Loads are unconditional
+  // (clamped row) so that they batch; the first two tiles are requested before the RoPE
+  // prologues so their HBM latency hides under them.
+  const bf16_t *kbase = a.kc + (int64_t)kvh * a.cache_rows * 128;
+  const bf16_t *vbase = a.vc + (int64_t)kvh * a.cache_rows * 128;
+  constexpr int MAXC = 512 / nthr;  // 1, 2, 4 or 8 chunks per thread
+  bf16x8 kA[MAXC], vA[MAXC], kB[MAXC], vB[MAXC];
+  const int old_max = S > 0 ? S - 1 : 0;
+  auto fetch = [&](bf16x8(&pk)[MAXC], bf16x8(&pv)[MAXC], int t) {
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = tid + i * nthr;
+      const int row = c >> 4, ch = c & 15;
+      int key = t * 32 + row;
+      key = key < old_max ? key : old_max;
+      pk[i] = *reinterpret_cast<const bf16x8 *>(kbase + (int64_t)key * 128 + ch * 8);
+      pv[i] = *reinterpret_cast<const bf16x8 *>(vbase + (int64_t)key * 128 + ch * 8);
+    }
+  };
+  auto stage = [&](bf16x8(&pk)[MAXC], bf16x8(&pv)[MAXC], int t) {
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = tid + i * nthr;
+      const int row = c >> 4, ch = c & 15;
+      int key = t * 32 + row;
+      key = key < kv_len ? key : kv_len - 1;
+      bf16x8 kk = pk[i], vv = pv[i];
+      if (key >= S) {
+        kk = *reinterpret_cast<const bf16x8 *>(&new_k[key - S][ch * 8]);
+        vv = *reinterpret_cast<const bf16x8 *>(&new_v[key - S][ch * 8]);
+      }
+      *reinterpret_cast<bf16x8 *>(lds_k + row * 256 + ((ch ^ (row & 15)) << 4)) = kk;
+      *reinterpret_cast<bf16x8 *>(lds_v + row * 256 + ((((ch >> 1) ^ (row & 7)) << 5) | ((ch & 1) << 4))) = vv;
+    }
+  };
+  if (t0 < t1) fetch(kA, vA, t0);
+  if (t0 + 1 < t1) fetch(kB, vB, t0 + 1);
+
+  // ---- phase 0: the 16 q rows of this wave's head, all in flight together
+  {
+    int brow[16], col[16], pos[16];
+    bool rp[16];
+    float o1[16], o2[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      brow[j] = j < bs ? a.blk_row0 + j : -1;
+      col[j] = a.q_col + head * 128;
+      pos[j] = pos0 + tau + j;
+      rp[j] = true;
+    }
+    rope_items<16>(a, brow, col, pos, rp, a.q_w, l, o1, o2);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      q_lds[wv][j][l] = f2bf(j < bs ? o1[j] : 0.f);
+      q_lds[wv][j][l + 64] = f2bf(j < bs ? o2[j] : 0.f);
+    }
+  }
+  STAMP(1);
+  // ---- phase 1 (last split): new K / V rows of this kv head, 8 items per wave per pass
+  if (is_last_split) {
+    for (int base = 0; base < 2 * n_new; base += 8 * G) {
+      int brow[8], col[8], pos[8], rel[8];
+      bool rp[8], isv[8];
+      float o1[8], o2[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int it = base + i * G + wv;
+        isv[i] = it >= n_new;
+        rel[i] = isv[i] ? it - n_new : it;
+        const bool ok = it < 2 * n_new;
+        brow[i] = !ok ? -1 : (rel[i] < tau ? a.ctx_row0 + rel[i] : a.blk_row0 + (rel[i] - tau));
+        col[i] = (isv[i] ? a.v_col : a.k_col) + kvh * 128;
+        pos[i] = pos0 + rel[i];
+        rp[i] = !isv[i];
+      }
+      rope_items<8>(a, brow, col, pos, rp, a.k_w, l, o1, o2);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (brow[i] >= 0) {
+          bf16_t *lrow = isv[i] ? new_v[rel[i]] : new_k[rel[i]];
+          lrow[l] = f2bf(o1[i]);
+          lrow[l + 64] = f2bf(o2[i]);
+          const int crow = S + rel[i];
+          if (crow < a.cache_rows) {
+            bf16_t *dst = (isv[i] ? a.vc : a.kc) + ((int64_t)kvh * a.cache_rows + crow) * 128;
+            dst[l] = f2bf(o1[i]);
+            dst[l + 64] = f2bf(o2[i]);
+          }
+        }
+    }
+  }
+  __syncthreads();
+  STAMP(2);
+
+  const int qi = l & 15, g = l >> 4;
+  bf16x8 qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8 *>(&q_lds[wv][qi][s * 32 + g * 8]);
+
+  f32x4 o[8];
+#pragma unroll
+  for (int dt = 0; dt < 8; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+
+  // ---- phase 2
+  auto compute_tile = [&](int t) {
+    f32x4 sc[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      sc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int row = u * 16 + qi;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int ch = s * 4 + g;
+        const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(lds_k + row * 256 + ((ch ^ qi) << 4));
+        sc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[s], sc[u], 0, 0, 0);
+      }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = t * 32 + u * 16 + 4 * g + r;
+        const bool vis = key < kv_len && (!a.causal || key <= qbase + qi);
+        const float v = vis ? sc[u][r] * a.scale_log2 : -INFINITY;
+        sc[u][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float m_ref = m_new == -INFINITY ? 0.f : m_new;
+    const float alpha = exp2f(m_run - m_ref);
+    m_run = m_new;
+    float psum = 0.f;
+    bf16x8 pb;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = exp2f(sc[u][r] - m_ref);
+        psum += p;
+        pb[u * 4 + r] = f2bf(p);
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) o[dt] *= alpha;
+    const int qq = (l & 15) >> 2, p = l & 3;
+    const int r0 = 4 * g + qq, r1 = 16 + 4 * g + qq;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) {
+      const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+          (lds_bf16x4 *)(lds_v + r0 * 256 + (((dt ^ (r0 & 7)) << 5) | (p << 3))));
+      const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+          (lds_bf16x4 *)(lds_v + r1 * 256 + (((dt ^ (r1 & 7)) << 5) | (p << 3))));
+      const bf16x8 va = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb, o[dt], 0, 0, 0);
+    }
+  };
+
+  for (int t = t0; t < t1; t += 2) {
+    stage(kA, vA, t);
+    __syncthreads();
+    if (t + 2 < t1) fetch(kA, vA, t + 2);
+    compute_tile(t);
+    __syncthreads();
+    if (t + 1 < t1) {
+      stage(kB, vB, t + 1);
+      __syncthreads();
+      if (t + 3 < t1) fetch(kB, vB, t + 3);
+      compute_tile(t + 1);
+      __syncthreads();
+    }
+  }
+  STAMP(3);
+
+  float l_tot = l_run + __shfl_xor(l_run, 16, 64);
+  l_tot += __shfl_xor(l_tot, 32, 64);
+  bf16_t *outp = reinterpret_cast<bf16_t *>(a.out_frag);
+
+  if (nsplit == 1) {  // lane (q, g): o[dt][r] = O[q][dt*16 + 4g + r]
+    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) {
+      const int col = head * 128 + dt * 16 + 4 * g;
+      bf16x4 w4 = {f2bf(o[dt][0] * inv), f2bf(o[dt][1] * inv), f2bf(o[dt][2] * inv), f2bf(o[dt][3] * inv)};
+      *reinterpret_cast<bf16x4 *>(outp + ((int64_t)(col >> 3) * 16 + qi) * 8 + (col & 7)) = w4;
+    }
+    return;
+  }
+
+  // ---- partials, then the last arriver of this kv head merges
+  {
+    float *op = a.o_part + (((int64_t)split * a.n_q + head) * 16 + qi) * 128;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) *reinterpret_cast<f32x4 *>(op + dt * 16 + 4 * g) = o[dt];
+    if (g == 0) {
+      float *ml = a.ml_part + (((int64_t)split * a.n_q + head) * 16 + qi) * 2;
+      ml[0] = m_run;
+      ml[1] = l_tot;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  STAMP(4);
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int ticket = __hip_atomic_fetch_add(&a.tickets[kvh], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = ticket == nsplit - 1;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(&a.tickets[kvh], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  STAMP(5);
+  if (!s_last) return;
+
+  // thread (q, 8-column group) merges NH heads of the group per pass
+  {
+    constexpr int NH = G >= 4 ? 4 : G;                 // heads per thread per pass
+    constexpr int NG = nthr >= 256 ? nthr / 256 : 1;   // head batches handled side by side
+    const int q = (tid >> 4) & 15, dg = tid & 15;
+    if (nthr >= 256) {
+      for (int hb = (tid >> 8) * NH; hb < G; hb += NG * NH) {
+        bf16x8 r[NH];
+        merge_items<NH>(a.o_part, a.ml_part, nsplit, a.n_q, kvh * G + hb, q, dg, r);
+#pragma unroll
+        for (int h = 0; h < NH; ++h) a.out_frag[((kvh * G + hb + h) * 16 + dg) * 16 + q] = r[h];
+      }
+    } else {  // G = 1 or 2: fewer than 256 threads, each covers several (q, dg) pairs
+      for (int it = tid; it < 256; it += nthr) {
+        bf16x8 r[NH];
+        merge_items<NH>(a.o_part, a.ml_part, nsplit, a.n_q, kvh * G, it >> 4, it & 15, r);
+#pragma unroll
+        for (int h = 0; h < NH; ++h) a.out_frag[((kvh * G + h) * 16 + (it & 15)) * 16 + (it >> 4)] = r[h];
+      }
+    }
+  }
+  STAMP(6);
+}
+
+}  // namespace
+
+#ifdef DFL_ATTN_STAMPS
+extern "C" int dfl_debug_read_stamps(unsigned long long *host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16);
+}
+#endif
+
+extern "C" int64_t dfl_attn_fused_ws_bytes(int n_q, int n_kv, int max_splits) {
+  return dfl_attn_ws_bytes(n_q, max_splits) + (int64_t)n_kv * sizeof(int) + 64;
+}
+
+extern "C" int dfl_attn_fused(const float *qkv, int nsplit, int64_t split_stride, int ld, int q_col, int k_col,
+                              int v_col, int ctx_row0, int blk_row0, int n_q, int n_kv, const void *q_norm_w,
+                              const void *k_norm_w, float eps, const void *cos_tab, const void *sin_tab, int max_pos,
+                              void *kcache, void *vcache, int cache_rows, float scale, int causal,
+                              const int32_t *dyn, int kv_len_max, void *ws, int max_splits, void *out_frag,
+                              void *stream) {
+  DFL_REQUIRE(qkv && cos_tab && sin_tab && kcache && vcache && dyn && out_frag && ws, "dfl_attn_fused: null pointer");
+  DFL_REQUIRE((q_norm_w == nullptr) == (k_norm_w == nullptr), "dfl_attn_fused: give both norm weights or neither");
+  DFL_REQUIRE(n_q > 0 && n_kv > 0 && n_q % n_kv == 0, "dfl_attn_fused: bad head counts");
+  DFL_REQUIRE(nsplit >= 1 && ld > 0 && q_col >= 0 && k_col >= 0 && v_col >= 0 && blk_row0 >= 0 && max_pos > 0,
+              "dfl_attn_fused: bad layout");
+  DFL_REQUIRE(kv_len_max > 0 && kv_len_max <= cache_rows && max_splits >= 1, "dfl_attn_fused: bad kv_len_max/max_splits");
+  // ~4 key tiles (128 keys) per split
+  const int ntiles = (kv_len_max + 31) / 32;
+  int ns = ntiles / 4;
+  ns = ns < 1 ? 1 : (ns > max_splits ? max_splits : ns);
+  FusedAttnArgs a{};
+  a.qkv = qkv;
+  a.nsplit_k = nsplit;
+  a.split_stride = split_stride;
+  a.ld = ld;
+  a.q_col = q_col;
+  a.k_col = k_col;
+  a.v_col = v_col;
+  a.ctx_row0 = ctx_row0;
+  a.blk_row0 = blk_row0;
+  a.q_w = (const bf16_t *)q_norm_w;
+  a.k_w = (const bf16_t *)k_norm_w;
+  a.eps = eps;
+  a.cos_tab = (const bf16_t *)cos_tab;
+  a.sin_tab = (const bf16_t *)sin_tab;
+  a.max_pos = max_pos;
+  a.kc = (bf16_t *)kcache;
+  a.vc = (bf16_t *)vcache;
+  a.cache_rows = cache_rows;
+  a.n_q = n_q;
+  a.n_kv = n_kv;
+  a.G = n_q / n_kv;
+  a.scale_log2 = scale * 1.4426950408889634f;
+  a.causal = causal ? 1 : 0;
+  a.dyn = dyn;
+  a.out_frag = (bf16x8 *)out_frag;
+  a.o_part = (float *)ws;
+  a.ml_part = (float *)ws + (int64_t)max_splits * n_q * 16 * 128;
+  a.tickets = (int *)((char *)ws + dfl_attn_ws_bytes(n_q, max_splits));
+  const dim3 grid(n_kv, ns);
+  hipStream_t st = (hipStream_t)stream;
+  switch (a.G) {
+    case 1: hipLaunchKernelGGL(k_attn_fused<1>, grid, dim3(64), 0, st, a); break;
+    case 2: hipLaunchKernelGGL(k_attn_fused<2>, grid, dim3(128), 0, st, a); break;
+    case 4: hipLaunchKernelGGL(k_attn_fused<4>, grid, dim3(256), 0, st, a); break;
+    case 8: hipLaunchKernelGGL(k_attn_fused<8>, grid, dim3(512), 0, st, a); break;
+    default: DFL_REQUIRE(false, "dfl_attn_fused: GQA group %d not in {1,2,4,8}", a.G);
+  }
+  DFL_CHECK_LAUNCH("dfl_attn_fused");
   return DFL_OK;
 }

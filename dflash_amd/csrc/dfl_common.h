@@ -49,10 +49,18 @@ __device__ __forceinline__ float bf2f(bf16_t x) {
 // value after one bf16 rounding, kept in fp32 (where torch would have stored bf16)
 __device__ __forceinline__ float rbf(float x) { return bf2f((bf16_t)x); }
 
+// 64-lane sum, result in every lane.  Row-local steps are DPP moves (VALU speed): an
+// LDS-routed __shfl_xor butterfly costs ~100 cycles per step and serialised the RoPE
+// prologues (6 us per 16 rows, measured with scripts/dbg_attn_stamps.py); the four row
+// sums are then combined through readlane.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+  const int iv = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16)) +
+         __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

@@ -158,7 +158,7 @@ class DFlashDraftModel:
                 h=torch.zeros(16, H, dtype=BF16, device=d),
                 q_rot=torch.zeros(c.num_attention_heads, 16, 128, dtype=BF16, device=d),
                 part=torch.zeros(npart, dtype=torch.float32, device=d),
-                attn_ws=ops.attn_ws(c.num_attention_heads, self.max_splits, d),
+                attn_ws=ops.attn_fused_ws(c.num_attention_heads, c.num_key_value_heads, self.max_splits, d),
                 argmax_ws=ops.argmax_ws(d),
                 ids16=torch.zeros(16, dtype=torch.int64, device=d),
             )
@@ -258,14 +258,14 @@ class DFlashDraftModel:
                           ids=block_ids, h_out=ws["h"], dyn=dyn, dyn_word=ops.DYN_BS)
         for i, lw in enumerate(L):
             ops.gemm_f32(lw["qkv"], ws["ctx_frag"], ws["xn_frag"], 2, nqkv, H, self.ks_qkv, ws["part"])
-            ops.qknorm_rope_append(qkv=ws["part"], nsplit=self.ks_qkv, split_stride=32 * nqkv, ld=nqkv, q_col=0,
-                                   k_col=c.q_dim, v_col=c.q_dim + c.kv_dim, ctx_row0=0, blk_row0=16,
-                                   n_q=c.num_attention_heads, n_kv=c.num_key_value_heads, q_norm_w=lw["q_norm"],
-                                   k_norm_w=lw["k_norm"], eps=c.rms_norm_eps, cos_tab=cos, sin_tab=sin,
-                                   q_out=ws["q_rot"], kcache=cache.k[i], vcache=cache.v[i], dyn=dyn)
-            ops.block_attn(q=ws["q_rot"], kcache=cache.k[i], vcache=cache.v[i], n_q=c.num_attention_heads,
-                           n_kv=c.num_key_value_heads, scale=c.head_dim ** -0.5, dyn=dyn, kv_len_max=S + tau + bs,
-                           ws=ws["attn_ws"], max_splits=self.max_splits, out_frag=ws["attn_frag"])
+            layout = dict(qkv=ws["part"], nsplit=self.ks_qkv, split_stride=32 * nqkv, ld=nqkv, q_col=0,
+                          k_col=c.q_dim, v_col=c.q_dim + c.kv_dim, ctx_row0=0, blk_row0=16,
+                          n_q=c.num_attention_heads, n_kv=c.num_key_value_heads, q_norm_w=lw["q_norm"],
+                          k_norm_w=lw["k_norm"], eps=c.rms_norm_eps, cos_tab=cos, sin_tab=sin, kcache=cache.k[i],
+                          vcache=cache.v[i], dyn=dyn)
+            # one launch: q/k-norm + RoPE + KV append + attention + split merge
+            ops.attn_fused(**layout, scale=c.head_dim ** -0.5, kv_len_max=S + tau + bs, ws=ws["attn_ws"],
+                           max_splits=self.max_splits, out_frag=ws["attn_frag"])
             ops.gemm_f32(lw["o"], ws["attn_frag"], None, 1, H, c.q_dim, self.ks_o, ws["part"])
             ops.norm_pack(norm_w=lw["ln2"], frag=ws["xn_frag"], H=H, eps=c.rms_norm_eps, part=ws["part"],
                           nsplit=self.ks_o, part_split=16 * H, ldp=H, resid_in=ws["h"], h_out=ws["h"], dyn=dyn,

@@ -150,6 +150,23 @@ def block_attn(*, q, kcache, vcache, n_q, n_kv, scale, dyn, kv_len_max, ws, max_
                                _p(ws), max_splits, _p(out_frag, BF16, "out_frag"), _stream()), "dfl_block_attn")
 
 
+def attn_fused_ws(n_q: int, n_kv: int, max_splits: int, device) -> torch.Tensor:
+    """Zeroed workspace (split partials + arrival tickets) for attn_fused."""
+    return torch.zeros(lib().dfl_attn_fused_ws_bytes(n_q, n_kv, max_splits), dtype=torch.uint8, device=device)
+
+
+def attn_fused(*, qkv, nsplit, split_stride, ld, q_col, k_col, v_col, ctx_row0, blk_row0, n_q, n_kv, q_norm_w,
+               k_norm_w, eps, cos_tab, sin_tab, kcache, vcache, scale, dyn, kv_len_max, ws, max_splits, out_frag,
+               causal: bool = False) -> None:
+    assert kcache.shape == vcache.shape and kcache.dim() == 3 and kcache.shape[2] == 128
+    check(lib().dfl_attn_fused(
+        _p(qkv, F32, "qkv"), nsplit, split_stride, ld, q_col, k_col, v_col, ctx_row0, blk_row0, n_q, n_kv,
+        _p(q_norm_w, BF16, "q_norm_w"), _p(k_norm_w, BF16, "k_norm_w"), eps, _p(cos_tab, BF16, "cos"),
+        _p(sin_tab, BF16, "sin"), cos_tab.shape[0], _p(kcache, BF16, "kcache"), _p(vcache, BF16, "vcache"),
+        kcache.shape[1], scale, int(causal), _p(dyn, I32, "dyn"), kv_len_max, _p(ws), max_splits,
+        _p(out_frag, BF16, "out_frag"), _stream()), "dfl_attn_fused")
+
+
 def argmax(logits: torch.Tensor) -> torch.Tensor:
     """First-max-index argmax over the last axis, int64 (model/utils.py:28-29)."""
     if logits.dtype not in (BF16, F32):

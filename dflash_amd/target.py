@@ -113,7 +113,7 @@ class NativeTarget:
         z = lambda *s, dt=BF16: torch.zeros(*s, dtype=dt, device=dev)  # noqa: E731
         self.ws = dict(xn=z(16 * self.H), attn=z(16 * self.q_dim), act=z(16 * self.I), h=z(16, self.H),
                        q=z(self.n_q, 16, 128), part=z(npart, dt=torch.float32),
-                       attn_ws=ops.attn_ws(self.n_q, max_splits, dev), argmax_ws=ops.argmax_ws(dev),
+                       attn_ws=ops.attn_fused_ws(self.n_q, self.n_kv, max_splits, dev), argmax_ws=ops.argmax_ws(dev),
                        post=torch.zeros(16, dtype=torch.int64, device=dev))
         self._rope = None
         self._taps = {}
@@ -191,13 +191,11 @@ class NativeTarget:
                       h_out=ws["h"], dyn=dyn, dyn_word=ops.DYN_BS)
         for i, lw in enumerate(Ls):
             ops.gemm_f32(lw["qkv"], ws["xn"], None, 1, self.nqkv, H, self.ks_qkv, ws["part"])
-            ops.qknorm_rope_append(qkv=ws["part"], nsplit=self.ks_qkv, split_stride=16 * self.nqkv, ld=self.nqkv,
-                                   q_col=0, k_col=self.q_dim, v_col=self.q_dim + self.kv_dim, ctx_row0=0, blk_row0=0,
-                                   n_q=self.n_q, n_kv=self.n_kv, q_norm_w=lw["q_norm"], k_norm_w=lw["k_norm"],
-                                   eps=self.eps, cos_tab=cos, sin_tab=sin, q_out=ws["q"], kcache=cache.k[i],
-                                   vcache=cache.v[i], dyn=dyn)
-            ops.block_attn(q=ws["q"], kcache=cache.k[i], vcache=cache.v[i], n_q=self.n_q, n_kv=self.n_kv,
-                           scale=128 ** -0.5, dyn=dyn, kv_len_max=start + bs, ws=ws["attn_ws"],
+            layout = dict(qkv=ws["part"], nsplit=self.ks_qkv, split_stride=16 * self.nqkv, ld=self.nqkv, q_col=0,
+                          k_col=self.q_dim, v_col=self.q_dim + self.kv_dim, ctx_row0=0, blk_row0=0, n_q=self.n_q,
+                          n_kv=self.n_kv, q_norm_w=lw["q_norm"], k_norm_w=lw["k_norm"], eps=self.eps, cos_tab=cos,
+                          sin_tab=sin, kcache=cache.k[i], vcache=cache.v[i], dyn=dyn)
+            ops.attn_fused(**layout, scale=128 ** -0.5, kv_len_max=start + bs, ws=ws["attn_ws"],
                            max_splits=self.max_splits, out_frag=ws["attn"], causal=True)
             ops.gemm_f32(lw["o"], ws["attn"], None, 1, H, self.q_dim, self.ks_o, ws["part"])
             ops.norm_pack(norm_w=lw["ln2"], frag=ws["xn"], H=H, eps=self.eps, part=ws["part"], nsplit=self.ks_o,

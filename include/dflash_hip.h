@@ -146,6 +146,20 @@ int dfl_block_attn(const void *q, const void *kcache, const void *vcache, int ca
                    float scale, int causal, const int32_t *dyn, int kv_len_max, void *ws, int max_splits,
                    void *out_frag, void *stream);
 
+/* The whole attention stage of a block in ONE launch: q/k-norm + RoPE + KV append
+ * (model/dflash.py:71-85) + attention (:86-99, causal = 0; target verify, causal = 1)
+ * + the merge of the key splits, result as frag16 for o_proj.  Same arithmetic as
+ * dfl_qknorm_rope_append + dfl_block_attn (K/V rows bit-identical); the key axis is
+ * split over workgroups and merged by the last one to arrive.  tau + bs <= 32 new rows.
+ * ws: dfl_attn_fused_ws_bytes(n_q, n_kv, max_splits) bytes, ZEROED once by the caller
+ * (it holds the arrival tickets, which every launch leaves at zero again). */
+int64_t dfl_attn_fused_ws_bytes(int n_q, int n_kv, int max_splits);
+int dfl_attn_fused(const float *qkv, int nsplit, int64_t split_stride, int ld, int q_col, int k_col, int v_col,
+                   int ctx_row0, int blk_row0, int n_q, int n_kv, const void *q_norm_w, const void *k_norm_w,
+                   float eps, const void *cos_tab, const void *sin_tab, int max_pos, void *kcache, void *vcache,
+                   int cache_rows, float scale, int causal, const int32_t *dyn, int kv_len_max, void *ws,
+                   int max_splits, void *out_frag, void *stream);
+
 /* First-max-index argmax over the last axis (model/utils.py:28-29).
  * dtype: 0 = bf16, 1 = fp32.  ids int64 [rows]. */
 int dfl_argmax(const void *logits, int dtype, int rows, int64_t V, int64_t *ids, void *stream);

@@ -308,6 +308,64 @@ def test_qknorm_rope_without_norm(ops):
     assert torch.equal(kc[:, S:S + bs].cpu(), kr[0])
 
 
+@pytest.mark.parametrize("n_q,n_kv,S,tau,bs,causal", [(4, 2, 0, 3, 16, False), (8, 2, 37, 5, 12, False),
+                                                      (32, 8, 1024, 7, 16, False), (32, 4, 200, 16, 16, False),
+                                                      (32, 8, 1024, 0, 16, True), (8, 8, 45, 0, 9, True),
+                                                      (4, 2, 0, 0, 16, True), (32, 8, 1439, 16, 16, False),
+                                                      (32, 8, 3000, 3, 16, True), (8, 2, 127, 1, 2, False)])
+def test_attn_fused_equals_three_launch_path(ops, n_q, n_kv, S, tau, bs, causal):
+    """dfl_attn_fused (1 launch) vs dfl_qknorm_rope_append + dfl_block_attn (3 launches):
+    the appended K/V must be bit-identical, the attention output equal within the
+    rounding of a different key-split order, and both within tolerance of fp32 torch."""
+    from dflash_amd.model import _rope_tables
+    g = gen(S + n_q + bs)
+    ld = (n_q + 2 * n_kv) * 128
+    part = torch.randn(2, 32, ld, generator=g).to(dev())
+    qw = (1 + 0.1 * torch.randn(128, generator=g)).to(BF16).to(dev())
+    kw = (1 + 0.1 * torch.randn(128, generator=g)).to(BF16).to(dev())
+    cos, sin = _rope_tables(128, 1e6, 2048, dev())
+    rows = S + tau + bs + 8
+    k0 = torch.randn(n_kv, rows, 128, generator=g).to(BF16).to(dev())
+    v0 = torch.randn(n_kv, rows, 128, generator=g).to(BF16).to(dev())
+    dyn = torch.zeros(8, dtype=torch.int32, device=dev())
+    ops.set_dyn(dyn, S, tau, bs, S)
+    common = dict(qkv=part, nsplit=2, split_stride=32 * ld, ld=ld, q_col=0, k_col=n_q * 128, v_col=(n_q + n_kv) * 128,
+                  ctx_row0=0, blk_row0=16, n_q=n_q, n_kv=n_kv, q_norm_w=qw, k_norm_w=kw, eps=1e-6, cos_tab=cos,
+                  sin_tab=sin, dyn=dyn)
+    # reference path
+    k1, v1 = k0.clone(), v0.clone()
+    q1 = torch.zeros(n_q, 16, 128, dtype=BF16, device=dev())
+    out1 = torch.zeros(16 * n_q * 128, dtype=BF16, device=dev())
+    ops.qknorm_rope_append(**common, q_out=q1, kcache=k1, vcache=v1)
+    ops.block_attn(q=q1, kcache=k1, vcache=v1, n_q=n_q, n_kv=n_kv, scale=128 ** -0.5, dyn=dyn,
+                   kv_len_max=S + tau + bs, ws=ops.attn_ws(n_q, 32, dev()), max_splits=32, out_frag=out1,
+                   causal=causal)
+    # fused
+    k2, v2 = k0.clone(), v0.clone()
+    out2 = torch.zeros(16 * n_q * 128, dtype=BF16, device=dev())
+    fws = ops.attn_fused_ws(n_q, n_kv, 32, dev())
+    for _ in range(2):   # twice: the arrival tickets must be back at zero after a launch
+        out2.zero_()
+        ops.attn_fused(**common, kcache=k2, vcache=v2, scale=128 ** -0.5, kv_len_max=S + tau + bs, ws=fws,
+                       max_splits=32, out_frag=out2, causal=causal)
+    assert torch.equal(k1, k2) and torch.equal(v1, v2)
+    a = unfrag(out1, n_q * 128).float()[:bs]
+    b = unfrag(out2, n_q * 128).float()[:bs]
+    assert torch.isfinite(b).all()
+    assert (a - b).abs().max() <= 2 ** -6 * a.abs().max()
+    # fp32 reference from the appended cache
+    kv_len = S + tau + bs
+    G = n_q // n_kv
+    kk = k2[:, :kv_len].float().repeat_interleave(G, dim=0)
+    vv = v2[:, :kv_len].float().repeat_interleave(G, dim=0)
+    sc = torch.einsum("hqd,hkd->hqk", q1[:, :bs].float(), kk) * 128 ** -0.5
+    if causal:
+        mask = torch.arange(kv_len, device=dev())[None, :] > (S + tau + torch.arange(bs, device=dev()))[:, None]
+        sc = sc.masked_fill(mask[None], float("-inf"))
+    ref = torch.einsum("hqk,hkd->qhd", torch.softmax(sc, dim=-1), vv).reshape(bs, n_q * 128)
+    assert (b - ref).abs().max() <= 2 ** -6 * ref.abs().max()
+
+
 # ------------------------------------------------------------------ integer side, golden
 def test_argmax_golden(ops):
     z = np.load(os.path.join(H.GOLDEN, "argmax.npz"))
