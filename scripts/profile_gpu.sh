@@ -9,11 +9,13 @@ mkdir -p "$R/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
 mode=${1:-stats}
 if [ "$mode" = stats ]; then
+  rm -rf "$R/gpurun_out/prof_stats"
   timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_stats" -- \
     python3 "$R/bench.py" --steps 24 --warmup 2 --no-cpu-baseline > "$R/gpurun_out/prof_stats.json" 2> "$R/gpurun_out/prof_stats.err"
   echo "stats rc=$?"
 else
   for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf "$R/gpurun_out/pmc_$c"
     timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$R/gpurun_out/pmc_$c" -- \
       python3 "$R/bench.py" --steps 6 --warmup 1 --no-cpu-baseline --target-layers 2 > "$R/gpurun_out/pmc_$c.json" 2> "$R/gpurun_out/pmc_$c.err"
     rc=$?
