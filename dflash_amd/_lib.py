@@ -12,6 +12,16 @@ LIB_PATH = os.path.join(HERE, "lib", "libdflash_hip.so")
 
 _p, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
+
+class Rows(C.Structure):
+    """dfl_rows of include/dflash_hip.h."""
+    _fields_ = [("frag", C.c_void_p), ("rows", C.c_void_p), ("ld", C.c_int64), ("ss", C.c_void_p),
+                ("nss", C.c_int32), ("norm_w", C.c_void_p), ("eps", C.c_float), ("valid_word", C.c_int32),
+                ("mode", C.c_int32)]
+
+
+_r = C.POINTER(Rows)
+
 # name -> (restype, argtypes); mirrors include/dflash_hip.h one to one
 SIGNATURES = {
     "dfl_version": (_i, []),
@@ -20,10 +30,12 @@ SIGNATURES = {
     "dfl_pack_weight_gateup": (_i, [_p, _p, _p, _i, _i, _p]),
     "dfl_set_dyn": (_i, [_p, _i, _i, _i, _i, _p]),
     "dfl_pack_rows": (_i, [_p, _i64, _i, _i, _p, _p, _i, _p]),
-    "dfl_gemm_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p]),
-    "dfl_gemm_silu_mul": (_i, [_p, _p, _i, _i, _p, _p]),
+    "dfl_gemm_f32": (_i, [_p, _r, _r, _i, _i, _i, _i, _p, _p, _p]),
+    "dfl_gemm_silu_mul": (_i, [_p, _r, _i, _i, _p, _p, _p]),
+    "dfl_gemm_resid": (_i, [_p, _r, _i, _i, _p, _i64, _i, _p, _i64, _p, _p, _p]),
+    "dfl_embed_rows": (_i, [_p, _p, _p, _i, _p, _p, _i, _p]),
     "dfl_argmax_ws_bytes": (_i64, []),
-    "dfl_gemm_argmax": (_i, [_p, _p, _i, _i, _i, _i, _p, _i, _p, _p, _i, _p, _p]),
+    "dfl_gemm_argmax": (_i, [_p, _r, _i, _i, _i, _i, _p, _i, _p, _p, _i, _p, _p]),
     "dfl_norm_pack": (_i, [_p, _i, _i64, _i, _i, _p, _p, _p, _p, _p, _i64, _p, _f, _p, _i, _p, _i, _p]),
     "dfl_qknorm_rope_append": (_i, [_p, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _f, _p, _p, _i, _p, _p, _p, _i, _p,
                                     _i, _i, _p]),

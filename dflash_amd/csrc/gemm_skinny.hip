@@ -1,76 +1,150 @@
 // Skinny (M <= 32 rows) weight-streaming GEMM for gfx950.
 //
-// Shape of the problem: every nn.Linear of the draft step sees
-// at most 16 block rows (+ <=16 context rows), so each weight byte is used for
-// <= 32 rows and the kernel is bound by HBM: 3.3 GB of weights per cycle against
-// 8 TB/s.  Design:
-//   * weights are pre-packed (dfl_pack_weight) so a wave's 16-B-per-lane load is
-//     one contiguous 1 KiB run AND one MFMA 16x16x32 A fragment: HBM -> VGPR ->
-//     matrix core, no LDS, no shuffles (guide: "GEMV / M<=16: load straight to
-//     VGPRs, deep unroll, late vmcnt");
-//   * a 1024-thread workgroup = 16 waves splits K 16 ways; each wave keeps its
-//     K-slice of the activations (frag16 layout, written by the producer kernel)
-//     in registers for the whole launch and walks the workgroup's column tiles,
-//     prefetching the next tile's weights while the current one is in the MFMA;
-//   * per tile the 16 partial 16x16 tiles meet in LDS (double-buffered, one
-//     barrier per tile) and 256 threads finish: fp32 partial store, fused
-//     SiLU(gate)*up -> frag16, or the lm_head's running bf16 argmax;
-//   * grid.y splits K further when K/32 > 128 steps (fc K=5H, down K=I).
-// MFMA utilisation is a few percent by construction; the roofline is HBM.
+// Shape of the problem: every nn.Linear of the draft step and of the
+// target's verify sees at most 16 block rows (+ <=16 context rows), so each weight byte
+// is used for <= 32 rows and the kernel is bound by HBM.  Design:
+//   * weights are pre-packed (dfl_pack_weight) so a wave's 16-B-per-lane load is one
+//     contiguous 1 KiB run AND one MFMA 16x16x32 A fragment: HBM -> VGPR -> matrix core,
+//     no LDS, no shuffles (guide: "GEMV / M<=16: load straight to VGPRs, deep unroll,
+//     late vmcnt");
+//   * a 1024-thread workgroup = 16 waves splits K 16 ways and walks the workgroup's
+//     column tiles, prefetching the next item's weights while the current one is in the
+//     MFMA; per tile the 16 partial 16x16 tiles meet in LDS (double-buffered, one
+//     barrier per tile) and 256 threads finish it;
+//   * the activation operand comes from a row source (dfl_rows): ready-made frag16
+//     fragments, plain bf16 rows, or the residual stream + per-tile sums of squares, in
+//     which case the wave applies the RMSNorm itself while building its fragments —
+//     the norm between two GEMMs is then not a launch of its own;
+//   * epilogues: fp32 partials (K split over grid.y) / SiLU(gate)*up -> frag16 /
+//     running bf16 argmax (lm_head) / residual add -> h, taps, sums of squares;
+//   * K beyond 16 waves x 8 steps: either grid.y partials, or (CHUNKED) the workgroup
+//     loops over K chunks itself so that the epilogue sees finished sums.
+// MFMA utilisation is a few percent by construction; the roofline is HBM: every launch
+// costs ~3.6 us + bytes / 6.5 TB/s (scripts/bench_gemm.py).
 #include "dfl_common.h"
 
 namespace {
 
-enum { EPI_F32 = 0, EPI_SILU = 1, EPI_ARGMAX = 2 };
+enum { EPI_F32 = 0, EPI_SILU = 1, EPI_ARGMAX = 2, EPI_RESID = 3 };
+
+struct RowSrc {
+  const bf16x8 *frag;  // mode 0: frag16 [KS][64]
+  const bf16_t *rows;  // mode 1/2: row-major [16][K], row stride ld
+  int64_t ld;
+  const float *ss;     // mode 2: [nss][16] partial sums of squares per row
+  int nss;
+  const bf16_t *nw;    // mode 2: RMSNorm weight [K]
+  float eps;
+  int valid_word;      // dyn word with the number of valid rows, < 0: all 16
+  int mode;
+};
 
 struct GemmArgs {
-  const bf16x8 *wp;     // packed weights [ntiles][KS][64]
-  const bf16x8 *xf[2];  // frag16 activations per row tile [KS][64]
-  int KS;               // K / 32
-  int ntiles;           // N / 16
-  int nfr;              // k-steps per wave (<= FR)
+  const bf16x8 *wp;  // packed weights [ntiles][KS][64]
+  RowSrc src[2];
+  const int32_t *dyn;
+  int KS;      // K / 32
+  int ntiles;  // N / 16
+  int nfr;     // k-steps per wave per chunk (<= FR)
+  int nch;     // K chunks walked inside the workgroup (1 unless CHUNKED)
   // EPI_F32
-  float *out;           // [ksplit][MT*16][ldo]
+  float *out;  // [ksplit][MT*16][ldo]
   int ldo;
   // EPI_SILU
-  bf16_t *act;          // frag16 [I/8][16][8]
+  bf16_t *act;  // frag16 [I/8][16][8]
   // EPI_ARGMAX
-  int row0, nrows;      // rows [row0, row0+nrows) take part
-  const int32_t *dyn;
+  int row0, nrows;
   int nrows_word;
-  float *best_val;      // [gridDim.x][16]
-  int *best_idx;        // [gridDim.x][16]
-  bf16_t *logits;       // optional [16][N]
+  float *best_val;  // [gridDim.x][16]
+  int *best_idx;
+  bf16_t *logits;  // optional [16][N]
   int N;
+  // EPI_RESID
+  bf16_t *h_io;  // [16][ldh]: h <- bf16(h + bf16(acc)) (add_resid) or bf16(acc)
+  int64_t ldh;
+  int add_resid;
+  bf16_t *tap;  // optional second copy of the new rows, row stride ldtap
+  int64_t ldtap;
+  float *ss_out;  // [ntiles][16] sum over the tile's 16 columns of h_new^2
 };
 
 __device__ __forceinline__ bf16x8 ld_stream(const bf16x8 *p) { return __builtin_nontemporal_load(p); }
 
-template <int MT, int FR, int EPI>
+// sum over the 16 lanes of a DPP row, result in each of them
+__device__ __forceinline__ float row_sum16(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+  return v;
+}
+
+// B-operand fragment of k-step ks for lane l (m = l&15, kq = l>>4): x[m][ks*32 + kq*8 ..+8]
+__device__ __forceinline__ bf16x8 load_x(const RowSrc &s, int ks, int l, int nv, float rstd) {
+  const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (s.mode == 0) return s.frag[(size_t)ks * 64 + l];
+  const int m = l & 15, k0 = ks * 32 + (l >> 4) * 8;
+  const int mr = m < nv ? m : (nv > 0 ? nv - 1 : 0);  // never read past the caller's valid rows
+  bf16x8 v = *reinterpret_cast<const bf16x8 *>(s.rows + (int64_t)mr * s.ld + k0);
+  if (s.mode == 2) {  // Qwen3RMSNorm: weight * bf16(x * rstd), tf:modeling_qwen3.py:59-64
+    const bf16x8 wv = *reinterpret_cast<const bf16x8 *>(s.nw + k0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(wv[j]) * rbf(bf2f(v[j]) * rstd));
+  }
+  return m < nv ? v : z;
+}
+
+template <int MT, bool CHUNKED, int EPI>
 __global__ __launch_bounds__(1024) void k_gemm(GemmArgs a) {
+  constexpr int FR = CHUNKED ? 4 : (MT == 1 ? 8 : 4);
   // red[buf][wave][mt][256]: lane l owns floats 4l..4l+3 (its MFMA D regs)
   __shared__ float red[2][16][MT][256];
 
   const int tid = threadIdx.x;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l = tid & 63;
-  const int ks0 = (blockIdx.y * 16 + w) * a.nfr;
-  int nf = a.KS - ks0;
-  nf = nf < 0 ? 0 : (nf > a.nfr ? a.nfr : nf);
 
-  bf16x8 xr[MT][FR];
+  // ---- row validity and (mode 2) the rows' rstd, once per wave
+  int nv[MT];
+  float rstd[MT];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int f = 0; f < FR; ++f) {
-      bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-      xr[mt][f] = (f < nf) ? a.xf[mt][(size_t)(ks0 + f) * 64 + l] : z;
+  for (int mt = 0; mt < MT; ++mt) {
+    const RowSrc &s = a.src[mt];
+    nv[mt] = (s.valid_word >= 0 && a.dyn) ? a.dyn[s.valid_word] : 16;
+    rstd[mt] = 1.f;
+    if (s.mode == 2) {
+      const int m = l & 15, part = l >> 4;
+      float t = 0.f;
+      for (int i = part; i < s.nss; i += 4) t += s.ss[i * 16 + m];  // fixed order: reproducible
+      t += __shfl_xor(t, 16, 64);
+      t += __shfl_xor(t, 32, 64);
+      rstd[mt] = rsqrtf(t / (float)(a.KS * 32) + s.eps);
     }
+  }
 
-  // Tile sequence of this workgroup.  F32/ARGMAX: tiles bx, bx+G, bx+2G, ...
-  // SILU: the packed weight interleaves (gate tile p, up tile p), and the sequence
-  // walks pairs p = bx, bx+G, ... as gate,up,gate,up so that the finishing thread
-  // meets a pair's two sums in consecutive iterations.
+  auto ks0_of = [&](int c) { return ((blockIdx.y * a.nch + c) * 16 + w) * a.nfr; };
+  auto nf_of = [&](int c) {
+    int nf = a.KS - ks0_of(c);
+    return nf < 0 ? 0 : (nf > a.nfr ? a.nfr : nf);
+  };
+
+  // activations of the (single) chunk stay in registers for the launch
+  bf16x8 xr[MT][FR];
+  if (!CHUNKED) {
+    const int ks0 = ks0_of(0), nf = nf_of(0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int f = 0; f < FR; ++f) {
+        const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        xr[mt][f] = f < nf ? load_x(a.src[mt], ks0 + f, l, nv[mt], rstd[mt]) : z;
+      }
+  }
+
+  // ---- tile sequence of this workgroup.  F32/ARGMAX/RESID: tiles bx, bx+G, ...
+  // SILU: the packed weight interleaves (gate tile p, up tile p) and the sequence walks
+  // pairs p = bx, bx+G, ... as gate,up,gate,up: the finishing thread meets a pair's two
+  // sums in consecutive positions.
   const int stride = gridDim.x;
   int nseq;
   if (EPI == EPI_SILU) {
@@ -83,62 +157,61 @@ __global__ __launch_bounds__(1024) void k_gemm(GemmArgs a) {
     return EPI == EPI_SILU ? 2 * ((int)blockIdx.x + (j >> 1) * stride) + (j & 1) : (int)blockIdx.x + j * stride;
   };
 
-  // finishing-thread state (threads < 256 only)
+  // finishing thread f < MT*256: row m = (f&255)>>4, column nl = f&15 of the tile
   float best = -INFINITY;  // running argmax
   int bestn = 0x7fffffff;
-  float gate_sum = 0.f;    // SILU: the pair's gate sum, kept across one iteration
+  float gate_sum = 0.f;    // SILU: the pair's gate sum, kept across one position
   int arg_rows = 0;
   if (EPI == EPI_ARGMAX) {
     arg_rows = a.nrows;
     if (a.dyn && a.nrows_word >= 0) arg_rows = a.dyn[a.nrows_word] - a.row0;
   }
 
-  auto load_tile = [&](bf16x8(&wr)[FR], int t) {
+  auto load_item = [&](bf16x8(&wr)[FR], bf16x8(&xb)[MT][FR], int t, int c) {
+    const int ks0 = ks0_of(c), nf = nf_of(c);
     const bf16x8 *base = a.wp + ((size_t)t * a.KS + ks0) * 64 + l;
 #pragma unroll
     for (int f = 0; f < FR; ++f)
       if (f < nf) wr[f] = ld_stream(base + (size_t)f * 64);
+    if (CHUNKED) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int f = 0; f < FR; ++f)
+          if (f < nf) xb[mt][f] = load_x(a.src[mt], ks0 + f, l, nv[mt], 1.f);
+    }
   };
 
-  // `buf` doubles as the position parity in the sequence (0 = gate, 1 = up for SILU)
-  auto compute = [&](bf16x8(&wr)[FR], int t, const int buf) {
-    f32x4 acc[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int f = 0; f < FR; ++f)
-      if (f < nf) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[f], xr[mt][f], acc[mt], 0, 0, 0);
-      }
+  f32x4 acc[MT];
+
+  auto finish = [&](int t, int pos) {
+    const int buf = pos & 1;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f32x4 *>(&red[buf][w][mt][l * 4]) = acc[mt];
     __syncthreads();
-
-    // D layout of mfma 16x16x32 (A = W rows n, B = x^T cols m): lane L reg r ->
-    // n_local = 4*(L>>4) + r, m = L & 15.  Thread `oo` finishes float oo of a tile.
+    // D layout of mfma 16x16x32 (A = W rows n, B = x^T cols m): lane L reg r holds
+    // n_local = 4*(L>>4) + r, m = L & 15, i.e. float 4L + r of the wave's slot.
     if (tid < MT * 256) {
-      const int mt = tid >> 8, oo = tid & 255;
+      const int mt = tid >> 8, ff = tid & 255;
+      const int m = ff >> 4, nl = ff & 15;
+      const int idx = 4 * (m + 16 * (nl >> 2)) + (nl & 3);
       float s = 0.f;
 #pragma unroll
-      for (int ww = 0; ww < 16; ++ww) s += red[buf][ww][mt][oo];
-      const int L = oo >> 2, r = oo & 3;
-      const int m = L & 15, nl = 4 * (L >> 4) + r;
+      for (int ww = 0; ww < 16; ++ww) s += red[buf][ww][mt][idx];
       if (EPI == EPI_F32) {
         a.out[((size_t)(blockIdx.y * MT + mt) * 16 + m) * a.ldo + t * 16 + nl] = s;
       } else if (EPI == EPI_SILU) {
         if (buf == 0) {
           gate_sum = s;
         } else {
-          // tf:...modeling_qwen3.py:82: gate/up Linear outputs are bf16, silu is
-          // evaluated in fp32 and rounded, the product is rounded again.
+          // tf:modeling_qwen3.py:82: gate/up Linear outputs are bf16, silu is evaluated in
+          // fp32 and rounded, the product is rounded again.
           const float gb = rbf(gate_sum), ub = rbf(s);
           const float act = rbf(gb / (1.f + __expf(-gb)));
           const int n = (t >> 1) * 16 + nl;
           a.act[((size_t)(n >> 3) * 16 + m) * 8 + (n & 7)] = f2bf(act * ub);
         }
-      } else {
+      } else if (EPI == EPI_ARGMAX) {
         const int n = t * 16 + nl;
         const float vb = rbf(s);  // lm_head output is bf16 before argmax (model/dflash.py:238,247)
         const bool live = (m >= a.row0) && (m < a.row0 + arg_rows);
@@ -148,31 +221,69 @@ __global__ __launch_bounds__(1024) void k_gemm(GemmArgs a) {
           best = vb;
           bestn = n;
         }
+      } else {  // EPI_RESID: model/dflash.py:140,144 residual adds (bf16 + bf16 -> bf16)
+        const int n = t * 16 + nl;
+        const float v = rbf(s);  // the Linear's bf16 output
+        bf16_t *hp = a.h_io + (int64_t)m * a.ldh + n;
+        const float hn = a.add_resid ? rbf(bf2f(*hp) + v) : v;
+        *hp = f2bf(hn);
+        if (a.tap) a.tap[(int64_t)m * a.ldtap + n] = f2bf(hn);
+        const float q = row_sum16(hn * hn);  // the 16 threads of row m are one DPP row
+        if (nl == 0 && a.ss_out) a.ss_out[t * 16 + m] = q;
       }
     }
   };
 
+  auto process = [&](bf16x8(&wr)[FR], bf16x8(&xb)[MT][FR], int t, int c, int pos) {
+    const int nf = nf_of(c);
+    if (c == 0) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int f = 0; f < FR; ++f)
+      if (f < nf) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[f], CHUNKED ? xb[mt][f] : xr[mt][f], acc[mt], 0, 0, 0);
+      }
+    if (c == a.nch - 1) finish(t, pos);
+  };
+
+  // items (position j in the sequence, chunk c), weights double-buffered A/B
   bf16x8 wA[FR], wB[FR];
-  if (nseq > 0) {
-    load_tile(wA, tile_of(0));
-    for (int j = 0;; j += 2) {
-      if (j + 1 < nseq) load_tile(wB, tile_of(j + 1));
-      compute(wA, tile_of(j), 0);
-      if (j + 1 >= nseq) break;
-      if (j + 2 < nseq) load_tile(wA, tile_of(j + 2));
-      compute(wB, tile_of(j + 1), 1);
-      if (j + 2 >= nseq) break;
+  bf16x8 xA[MT][FR], xB[MT][FR];
+  const int nitems = nseq * a.nch;
+  if (nitems > 0) {
+    int j = 0, c = 0;  // current item
+    load_item(wA, xA, tile_of(0), 0);
+    for (int i = 0;; i += 2) {
+      int jn = j, cn = c + 1;  // item i+1
+      if (cn == a.nch) {
+        cn = 0;
+        ++jn;
+      }
+      if (i + 1 < nitems) load_item(wB, xB, tile_of(jn), cn);
+      process(wA, xA, tile_of(j), c, j);
+      if (i + 1 >= nitems) break;
+      int j2 = jn, c2 = cn + 1;  // item i+2
+      if (c2 == a.nch) {
+        c2 = 0;
+        ++j2;
+      }
+      if (i + 2 < nitems) load_item(wA, xA, tile_of(j2), c2);
+      process(wB, xB, tile_of(jn), cn, jn);
+      if (i + 2 >= nitems) break;
+      j = j2;
+      c = c2;
     }
   }
 
   if (EPI == EPI_ARGMAX) {
-    // threads 4m+r (+64*wave) of waves 0..3 share row m: reduce 4 lanes, then 4 waves
-    __syncthreads();
-    float *sv = &red[0][0][0][0];
-    int *si = reinterpret_cast<int *>(&red[1][0][0][0]);
+    // the 16 threads of row m are consecutive lanes: shuffle down to lane nl == 0
     if (tid < 256) {
 #pragma unroll
-      for (int o = 1; o <= 2; o <<= 1) {
+      for (int o = 1; o <= 8; o <<= 1) {
         const float ov = __shfl_xor(best, o, 64);
         const int oi = __shfl_xor(bestn, o, 64);
         if (ov > best || (ov == best && oi < bestn)) {
@@ -180,26 +291,10 @@ __global__ __launch_bounds__(1024) void k_gemm(GemmArgs a) {
           bestn = oi;
         }
       }
-      if ((l & 3) == 0) {
-        sv[w * 16 + (l >> 2)] = best;
-        si[w * 16 + (l >> 2)] = bestn;
+      if ((tid & 15) == 0) {
+        a.best_val[blockIdx.x * 16 + (tid >> 4)] = best;
+        a.best_idx[blockIdx.x * 16 + (tid >> 4)] = bestn;
       }
-    }
-    __syncthreads();
-    if (tid < 16) {
-      float bv = sv[tid];
-      int bi = si[tid];
-#pragma unroll
-      for (int ww = 1; ww < 4; ++ww) {
-        const float ov = sv[ww * 16 + tid];
-        const int oi = si[ww * 16 + tid];
-        if (ov > bv || (ov == bv && oi < bi)) {
-          bv = ov;
-          bi = oi;
-        }
-      }
-      a.best_val[blockIdx.x * 16 + tid] = bv;
-      a.best_idx[blockIdx.x * 16 + tid] = bi;
     }
   }
 }
@@ -251,16 +346,67 @@ __global__ void k_pack_weight(const bf16x8 *__restrict__ w, bf16x8 *__restrict__
   }
 }
 
-int pick_ksplit(int KS, int fr_max) { return (KS + 16 * fr_max - 1) / (16 * fr_max); }
+// h[m] = embed[ids[m]] (bf16 rows) and the rows' sums of squares (one partial per row)
+__global__ __launch_bounds__(256) void k_embed_rows(const bf16_t *embed, const int64_t *ids, bf16_t *h, int H,
+                                                    float *ss_out, const int32_t *dyn, int dyn_word) {
+  __shared__ float wsum[4];
+  const int m = blockIdx.x, tid = threadIdx.x;
+  const int nv = dyn ? dyn[dyn_word] : 16;
+  float ss = 0.f;
+  if (m < nv) {
+    const bf16_t *src = embed + ids[m] * (int64_t)H;
+    for (int c = tid; c < (H >> 3); c += 256) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8 *>(src + c * 8);
+      *reinterpret_cast<bf16x8 *>(h + (int64_t)m * H + c * 8) = v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss += bf2f(v[j]) * bf2f(v[j]);
+    }
+  }
+  ss = wave_sum(ss);
+  if ((tid & 63) == 0) wsum[tid >> 6] = ss;
+  __syncthreads();
+  if (tid == 0) ss_out[m] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+int pick_ksplit_min(int KS, int fr_max) { return (KS + 16 * fr_max - 1) / (16 * fr_max); }
+
+// Workgroups along x for `ngroups` tile groups when the K axis is cut `ksplit` ways: at
+// most 256 workgroups in all (one 16-wave workgroup per CU), every workgroup walking the
+// same number of groups so that no CU streams twice as long as its neighbour.
+int grid_x_for(int ngroups, int ksplit = 1) {
+  int gx_max = 256 / ksplit;
+  if (gx_max < 1) gx_max = 1;
+  const int per_wg = (ngroups + gx_max - 1) / gx_max;
+  return (ngroups + per_wg - 1) / per_wg;
+}
+
+bool fill_src(RowSrc &d, const dfl_rows *s, int K, const char *who) {
+  if (!s) {
+    dfl_set_error("%s: null row source", who);
+    return false;
+  }
+  d.frag = (const bf16x8 *)s->frag;
+  d.rows = (const bf16_t *)s->rows;
+  d.ld = s->ld;
+  d.ss = s->ss;
+  d.nss = s->nss;
+  d.nw = (const bf16_t *)s->norm_w;
+  d.eps = s->eps;
+  d.valid_word = s->valid_word;
+  d.mode = s->mode;
+  const bool ok = (s->mode == 0 && s->frag) || (s->mode == 1 && s->rows && s->ld >= K && s->ld % 8 == 0) ||
+                  (s->mode == 2 && s->rows && s->ss && s->nss >= 1 && s->norm_w && s->ld >= K && s->ld % 8 == 0);
+  if (!ok) dfl_set_error("%s: bad row source (mode %d)", who, s->mode);
+  return ok;
+}
 
 }  // namespace
 
 extern "C" int dfl_pack_weight(const void *w, void *wp, int N, int K, void *stream) {
   DFL_REQUIRE(w && wp, "dfl_pack_weight: null pointer");
   DFL_REQUIRE(N > 0 && K > 0 && N % 16 == 0 && K % 32 == 0, "dfl_pack_weight: need N%%16==0, K%%32==0 (N=%d K=%d)", N, K);
-  const int ntiles = N / 16, KS = K / 32;
   hipLaunchKernelGGL(k_pack_weight, dim3(2048), dim3(256), 0, (hipStream_t)stream, (const bf16x8 *)w, (bf16x8 *)wp,
-                     ntiles, KS, 1, 0);
+                     N / 16, K / 32, 1, 0);
   DFL_CHECK_LAUNCH("dfl_pack_weight");
   return DFL_OK;
 }
@@ -268,99 +414,137 @@ extern "C" int dfl_pack_weight(const void *w, void *wp, int N, int K, void *stre
 extern "C" int dfl_pack_weight_gateup(const void *gate, const void *up, void *wp, int I, int K, void *stream) {
   DFL_REQUIRE(gate && up && wp, "dfl_pack_weight_gateup: null pointer");
   DFL_REQUIRE(I > 0 && K > 0 && I % 16 == 0 && K % 32 == 0, "dfl_pack_weight_gateup: need I%%16==0, K%%32==0");
-  const int ntiles = I / 16, KS = K / 32;
   hipLaunchKernelGGL(k_pack_weight, dim3(2048), dim3(256), 0, (hipStream_t)stream, (const bf16x8 *)gate,
-                     (bf16x8 *)wp, ntiles, KS, 2, 0);
+                     (bf16x8 *)wp, I / 16, K / 32, 2, 0);
   hipLaunchKernelGGL(k_pack_weight, dim3(2048), dim3(256), 0, (hipStream_t)stream, (const bf16x8 *)up, (bf16x8 *)wp,
-                     ntiles, KS, 2, 1);
+                     I / 16, K / 32, 2, 1);
   DFL_CHECK_LAUNCH("dfl_pack_weight_gateup");
   return DFL_OK;
 }
 
-// Workgroups along x for `ngroups` tile groups when the K axis is cut `ksplit` ways: at
-// most 256 workgroups in all (one 16-wave workgroup per CU), every workgroup walking
-// the same number of groups so that no CU streams twice as long as its neighbour.
-static int grid_x_for(int ngroups, int ksplit = 1) {
-  int gx_max = 256 / ksplit;
-  if (gx_max < 1) gx_max = 1;
-  const int per_wg = (ngroups + gx_max - 1) / gx_max;
-  return (ngroups + per_wg - 1) / per_wg;
+extern "C" int dfl_embed_rows(const void *embed, const int64_t *ids, void *h_out, int H, float *ss_out,
+                              const int32_t *dyn, int dyn_word, void *stream) {
+  DFL_REQUIRE(embed && ids && h_out && ss_out, "dfl_embed_rows: null pointer");
+  DFL_REQUIRE(H > 0 && H % 8 == 0, "dfl_embed_rows: H%%8 != 0");
+  hipLaunchKernelGGL(k_embed_rows, dim3(16), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)embed, ids,
+                     (bf16_t *)h_out, H, ss_out, dyn, dyn_word);
+  DFL_CHECK_LAUNCH("dfl_embed_rows");
+  return DFL_OK;
 }
 
-extern "C" int dfl_gemm_f32(const void *wp, const void *xf0, const void *xf1, int mt, int N, int K, int ksplit,
-                            float *out, void *stream) {
-  DFL_REQUIRE(wp && xf0 && out, "dfl_gemm_f32: null pointer");
-  DFL_REQUIRE(mt == 1 || (mt == 2 && xf1), "dfl_gemm_f32: mt must be 1 or 2 (with xf1)");
+extern "C" int dfl_gemm_f32(const void *wp, const dfl_rows *x0, const dfl_rows *x1, int mt, int N, int K, int ksplit,
+                            float *out, const int32_t *dyn, void *stream) {
+  DFL_REQUIRE(wp && out, "dfl_gemm_f32: null pointer");
+  DFL_REQUIRE(mt == 1 || mt == 2, "dfl_gemm_f32: mt must be 1 or 2");
   DFL_REQUIRE(N > 0 && K > 0 && N % 16 == 0 && K % 32 == 0, "dfl_gemm_f32: need N%%16==0, K%%32==0 (N=%d K=%d)", N, K);
   const int KS = K / 32;
   const int fr_max = mt == 1 ? 8 : 4;
-  DFL_REQUIRE(ksplit >= pick_ksplit(KS, fr_max) && ksplit <= 64, "dfl_gemm_f32: ksplit=%d too small for K=%d (need >= %d)",
-              ksplit, K, pick_ksplit(KS, fr_max));
+  DFL_REQUIRE(ksplit >= pick_ksplit_min(KS, fr_max) && ksplit <= 64, "dfl_gemm_f32: ksplit=%d too small for K=%d (need >= %d)",
+              ksplit, K, pick_ksplit_min(KS, fr_max));
   GemmArgs a{};
+  if (!fill_src(a.src[0], x0, K, "dfl_gemm_f32")) return DFL_EINVAL;
+  if (mt == 2 && !fill_src(a.src[1], x1, K, "dfl_gemm_f32")) return DFL_EINVAL;
   a.wp = (const bf16x8 *)wp;
-  a.xf[0] = (const bf16x8 *)xf0;
-  a.xf[1] = (const bf16x8 *)xf1;
+  a.dyn = dyn;
   a.KS = KS;
   a.ntiles = N / 16;
   a.nfr = (KS + 16 * ksplit - 1) / (16 * ksplit);
+  a.nch = 1;
   a.out = out;
   a.ldo = N;
   dim3 grid(grid_x_for(a.ntiles, ksplit), ksplit);
   if (mt == 1)
-    hipLaunchKernelGGL((k_gemm<1, 8, EPI_F32>), grid, dim3(1024), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((k_gemm<1, false, EPI_F32>), grid, dim3(1024), 0, (hipStream_t)stream, a);
   else
-    hipLaunchKernelGGL((k_gemm<2, 4, EPI_F32>), grid, dim3(1024), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((k_gemm<2, false, EPI_F32>), grid, dim3(1024), 0, (hipStream_t)stream, a);
   DFL_CHECK_LAUNCH("dfl_gemm_f32");
   return DFL_OK;
 }
 
-extern "C" int dfl_gemm_silu_mul(const void *wp_gateup, const void *xf, int I, int K, void *act_frag, void *stream) {
-  DFL_REQUIRE(wp_gateup && xf && act_frag, "dfl_gemm_silu_mul: null pointer");
+extern "C" int dfl_gemm_silu_mul(const void *wp_gateup, const dfl_rows *x, int I, int K, void *act_frag,
+                                 const int32_t *dyn, void *stream) {
+  DFL_REQUIRE(wp_gateup && act_frag, "dfl_gemm_silu_mul: null pointer");
   DFL_REQUIRE(I > 0 && K > 0 && I % 16 == 0 && K % 32 == 0, "dfl_gemm_silu_mul: need I%%16==0, K%%32==0");
   const int KS = K / 32;
   DFL_REQUIRE(KS <= 16 * 8, "dfl_gemm_silu_mul: K=%d needs a K split, which the fused activation cannot take", K);
   GemmArgs a{};
+  if (!fill_src(a.src[0], x, K, "dfl_gemm_silu_mul")) return DFL_EINVAL;
   a.wp = (const bf16x8 *)wp_gateup;
-  a.xf[0] = (const bf16x8 *)xf;
+  a.dyn = dyn;
   a.KS = KS;
   a.ntiles = 2 * (I / 16);
   a.nfr = (KS + 15) / 16;
+  a.nch = 1;
   a.act = (bf16_t *)act_frag;
-  dim3 grid(grid_x_for(I / 16), 1);
-  hipLaunchKernelGGL((k_gemm<1, 8, EPI_SILU>), grid, dim3(1024), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((k_gemm<1, false, EPI_SILU>), dim3(grid_x_for(I / 16), 1), dim3(1024), 0, (hipStream_t)stream, a);
   DFL_CHECK_LAUNCH("dfl_gemm_silu_mul");
   return DFL_OK;
 }
 
 extern "C" int64_t dfl_argmax_ws_bytes(void) { return 256 * 16 * (int64_t)(sizeof(float) + sizeof(int)); }
 
-extern "C" int dfl_gemm_argmax(const void *wp, const void *xf, int V, int K, int row0, int nrows, const int32_t *dyn,
-                               int nrows_dyn_word, void *ws, int64_t *out_ids, int out_off, void *logits,
-                               void *stream) {
-  DFL_REQUIRE(wp && xf && ws && out_ids, "dfl_gemm_argmax: null pointer");
+extern "C" int dfl_gemm_argmax(const void *wp, const dfl_rows *x, int V, int K, int row0, int nrows,
+                               const int32_t *dyn, int nrows_dyn_word, void *ws, int64_t *out_ids, int out_off,
+                               void *logits, void *stream) {
+  DFL_REQUIRE(wp && ws && out_ids, "dfl_gemm_argmax: null pointer");
   DFL_REQUIRE(V > 0 && K > 0 && V % 16 == 0 && K % 32 == 0, "dfl_gemm_argmax: need V%%16==0, K%%32==0 (V=%d K=%d)", V, K);
   DFL_REQUIRE(row0 >= 0 && nrows >= 0 && row0 + nrows <= 16, "dfl_gemm_argmax: rows [%d,%d) outside the 16-row tile", row0,
               row0 + nrows);
   const int KS = K / 32;
   DFL_REQUIRE(KS <= 16 * 8, "dfl_gemm_argmax: K=%d exceeds 4096 (argmax needs finished sums)", K);
   GemmArgs a{};
+  if (!fill_src(a.src[0], x, K, "dfl_gemm_argmax")) return DFL_EINVAL;
   a.wp = (const bf16x8 *)wp;
-  a.xf[0] = (const bf16x8 *)xf;
+  a.dyn = dyn;
   a.KS = KS;
   a.ntiles = V / 16;
   a.nfr = (KS + 15) / 16;
+  a.nch = 1;
   a.row0 = row0;
   a.nrows = nrows;
-  a.dyn = dyn;
   a.nrows_word = nrows_dyn_word;
   a.best_val = (float *)ws;
   a.best_idx = (int *)((char *)ws + 256 * 16 * sizeof(float));
   a.logits = (bf16_t *)logits;
   a.N = V;
   const int gx = grid_x_for(a.ntiles);
-  hipLaunchKernelGGL((k_gemm<1, 8, EPI_ARGMAX>), dim3(gx, 1), dim3(1024), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((k_gemm<1, false, EPI_ARGMAX>), dim3(gx, 1), dim3(1024), 0, (hipStream_t)stream, a);
   hipLaunchKernelGGL(k_argmax_finish, dim3(16), dim3(64), 0, (hipStream_t)stream, a.best_val, a.best_idx, gx, row0,
                      nrows, dyn, nrows_dyn_word, out_ids, out_off);
   DFL_CHECK_LAUNCH("dfl_gemm_argmax");
+  return DFL_OK;
+}
+
+extern "C" int dfl_gemm_resid(const void *wp, const dfl_rows *x, int N, int K, void *h_io, int64_t ldh,
+                              int add_residual, void *tap, int64_t ldtap, float *ss_out, const int32_t *dyn,
+                              void *stream) {
+  DFL_REQUIRE(wp && h_io, "dfl_gemm_resid: null pointer");
+  DFL_REQUIRE(N > 0 && K > 0 && N % 16 == 0 && K % 32 == 0, "dfl_gemm_resid: need N%%16==0, K%%32==0 (N=%d K=%d)", N, K);
+  DFL_REQUIRE(ldh >= N && (!tap || ldtap >= N), "dfl_gemm_resid: row strides shorter than N");
+  const int KS = K / 32;
+  GemmArgs a{};
+  if (!fill_src(a.src[0], x, K, "dfl_gemm_resid")) return DFL_EINVAL;
+  a.wp = (const bf16x8 *)wp;
+  a.dyn = dyn;
+  a.KS = KS;
+  a.ntiles = N / 16;
+  a.h_io = (bf16_t *)h_io;
+  a.ldh = ldh;
+  a.add_resid = add_residual ? 1 : 0;
+  a.tap = (bf16_t *)tap;
+  a.ldtap = ldtap;
+  a.ss_out = ss_out;
+  const dim3 grid(grid_x_for(a.ntiles), 1);
+  if (KS <= 16 * 8) {  // the whole K fits the 16 waves x 8 steps of one pass
+    a.nfr = (KS + 15) / 16;
+    a.nch = 1;
+    hipLaunchKernelGGL((k_gemm<1, false, EPI_RESID>), grid, dim3(1024), 0, (hipStream_t)stream, a);
+  } else {  // walk K in chunks of 16 waves x 4 steps inside the workgroup
+    DFL_REQUIRE(a.src[0].mode != 2, "dfl_gemm_resid: a normalised source needs K <= 4096");
+    a.nfr = 4;
+    a.nch = (KS + 63) / 64;
+    hipLaunchKernelGGL((k_gemm<1, true, EPI_RESID>), grid, dim3(1024), 0, (hipStream_t)stream, a);
+  }
+  DFL_CHECK_LAUNCH("dfl_gemm_resid");
   return DFL_OK;
 }

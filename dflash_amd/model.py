@@ -117,6 +117,7 @@ class DFlashDraftModel:
             del qkv
         torch.cuda.synchronize(self.device)
         self.w = w
+        self._ws = None  # row sources point at the weights: rebuild with them
         return self
 
     @classmethod
@@ -156,11 +157,27 @@ class DFlashDraftModel:
                 attn_frag=torch.zeros(16 * c.q_dim, dtype=BF16, device=d),
                 act_frag=torch.zeros(16 * I, dtype=BF16, device=d),
                 h=torch.zeros(16, H, dtype=BF16, device=d),
+                ctxh=torch.zeros(16, H, dtype=BF16, device=d),
+                ss_emb=torch.zeros(16, dtype=torch.float32, device=d),
+                ss_h=torch.zeros(H, dtype=torch.float32, device=d),       # [H/16 tiles][16 rows]
+                ss_ctx=torch.zeros(H, dtype=torch.float32, device=d),
                 q_rot=torch.zeros(c.num_attention_heads, 16, 128, dtype=BF16, device=d),
                 part=torch.zeros(npart, dtype=torch.float32, device=d),
                 attn_ws=ops.attn_fused_ws(c.num_attention_heads, c.num_key_value_heads, self.max_splits, d),
                 argmax_ws=ops.argmax_ws(d),
                 ids16=torch.zeros(16, dtype=torch.int64, device=d),
+            )
+            # row sources of the fused pipeline (pointers are fixed for the model's lifetime):
+            # the GEMM that consumes a normalised activation applies the RMSNorm itself
+            ws, eps, nt = self._ws, c.rms_norm_eps, H // 16
+            L = self.w["layers"]
+            self._src = dict(
+                ctx=ops.rows_normed(ws["ctxh"], ws["ss_ctx"], nt, self.w["hidden_norm"], eps, ops.DYN_TAU),
+                ln1_first=ops.rows_normed(ws["h"], ws["ss_emb"], 1, L[0]["ln1"], eps, ops.DYN_BS),
+                ln1=[ops.rows_normed(ws["h"], ws["ss_h"], nt, lw["ln1"], eps, ops.DYN_BS) for lw in L],
+                ln2=[ops.rows_normed(ws["h"], ws["ss_h"], nt, lw["ln2"], eps, ops.DYN_BS) for lw in L],
+                final=ops.rows_normed(ws["h"], ws["ss_h"], nt, self.w["norm"], eps, ops.DYN_BS),
+                attn=ops.rows_frag(ws["attn_frag"]), act=ops.rows_frag(ws["act_frag"]),
             )
         return self._ws
 
@@ -230,8 +247,8 @@ class DFlashDraftModel:
                     noise: Optional[torch.Tensor] = None, append: bool = True) -> torch.Tensor:
         """One draft forward over the block (model/dflash.py:166-190 for ctx <= 16 rows).
         Context rows `th_rows` [tau, fc_in] and the block (token ids + embedding table,
-        or a ready `noise` [bs, H]) -> final-normed hidden as frag16 (returned buffer is
-        scratch, valid until the next call).  K/V of tau+bs rows are written at cache
+        or a ready `noise` [bs, H]) -> the row source of the final-normed hidden states
+        (the lm_head GEMM applies the final RMSNorm; scratch, valid until the next call).  K/V of tau+bs rows are written at cache
         rows S.. ; `append` advances the host length by tau (the block rows are
         dropped again, as crop(start) does at :246)."""
         c, ws, w = self.config, self._workspace(), self.w
@@ -244,41 +261,34 @@ class DFlashDraftModel:
         nqkv = c.q_dim + 2 * c.kv_dim
         cos, sin = self._rope_tab(pos0 + tau + bs + 64)
         dyn = cache.dyn
+        src = self._src
         ops.set_dyn(dyn, S, tau, bs, pos0)
         if tau > 0:
-            self._ctx_rows(th_rows, tau, dyn, ops.DYN_TAU)
-        else:
-            ws["ctx_frag"].zero_()
+            # fc straight off the tap rows; hidden_norm is applied by each layer's qkv GEMM (:177)
+            ops.gemm_resid(w["fc"], ops.rows_plain(th_rows, ops.DYN_TAU), H, c.fc_in, ws["ctxh"], add_residual=False,
+                           ss_out=ws["ss_ctx"], dyn=dyn)
         L = w["layers"]
-        if noise is not None:
-            ops.norm_pack(norm_w=L[0]["ln1"], frag=ws["xn_frag"], H=H, eps=c.rms_norm_eps, resid_in=noise,
-                          h_out=ws["h"], dyn=dyn, dyn_word=ops.DYN_BS)
+        if noise is not None:  # public forward(): the caller embedded the block itself
+            ws["h"][:bs].copy_(noise[:bs])
+            ws["ss_emb"][:bs].copy_(noise[:bs].float().pow(2).sum(-1))
         else:
-            ops.norm_pack(norm_w=L[0]["ln1"], frag=ws["xn_frag"], H=H, eps=c.rms_norm_eps, embed=embed,
-                          ids=block_ids, h_out=ws["h"], dyn=dyn, dyn_word=ops.DYN_BS)
+            ops.embed_rows(embed, block_ids, ws["h"], H, ws["ss_emb"], dyn, ops.DYN_BS)
         for i, lw in enumerate(L):
-            ops.gemm_f32(lw["qkv"], ws["ctx_frag"], ws["xn_frag"], 2, nqkv, H, self.ks_qkv, ws["part"])
-            layout = dict(qkv=ws["part"], nsplit=self.ks_qkv, split_stride=32 * nqkv, ld=nqkv, q_col=0,
-                          k_col=c.q_dim, v_col=c.q_dim + c.kv_dim, ctx_row0=0, blk_row0=16,
-                          n_q=c.num_attention_heads, n_kv=c.num_key_value_heads, q_norm_w=lw["q_norm"],
-                          k_norm_w=lw["k_norm"], eps=c.rms_norm_eps, cos_tab=cos, sin_tab=sin, kcache=cache.k[i],
-                          vcache=cache.v[i], dyn=dyn)
+            x1 = src["ln1_first"] if i == 0 else src["ln1"][i]
+            ops.gemm_f32(lw["qkv"], src["ctx"], x1, 2, nqkv, H, self.ks_qkv, ws["part"], dyn)
             # one launch: q/k-norm + RoPE + KV append + attention + split merge
-            ops.attn_fused(**layout, scale=c.head_dim ** -0.5, kv_len_max=S + tau + bs, ws=ws["attn_ws"],
-                           max_splits=self.max_splits, out_frag=ws["attn_frag"])
-            ops.gemm_f32(lw["o"], ws["attn_frag"], None, 1, H, c.q_dim, self.ks_o, ws["part"])
-            ops.norm_pack(norm_w=lw["ln2"], frag=ws["xn_frag"], H=H, eps=c.rms_norm_eps, part=ws["part"],
-                          nsplit=self.ks_o, part_split=16 * H, ldp=H, resid_in=ws["h"], h_out=ws["h"], dyn=dyn,
-                          dyn_word=ops.DYN_BS)
-            ops.gemm_silu_mul(lw["gu"], ws["xn_frag"], I, H, ws["act_frag"])
-            ops.gemm_f32(lw["down"], ws["act_frag"], None, 1, H, I, self.ks_down, ws["part"])
-            nxt = L[i + 1]["ln1"] if i + 1 < len(L) else w["norm"]
-            ops.norm_pack(norm_w=nxt, frag=ws["xn_frag"], H=H, eps=c.rms_norm_eps, part=ws["part"],
-                          nsplit=self.ks_down, part_split=16 * H, ldp=H, resid_in=ws["h"], h_out=ws["h"], dyn=dyn,
-                          dyn_word=ops.DYN_BS)
+            ops.attn_fused(qkv=ws["part"], nsplit=self.ks_qkv, split_stride=32 * nqkv, ld=nqkv, q_col=0,
+                           k_col=c.q_dim, v_col=c.q_dim + c.kv_dim, ctx_row0=0, blk_row0=16,
+                           n_q=c.num_attention_heads, n_kv=c.num_key_value_heads, q_norm_w=lw["q_norm"],
+                           k_norm_w=lw["k_norm"], eps=c.rms_norm_eps, cos_tab=cos, sin_tab=sin, kcache=cache.k[i],
+                           vcache=cache.v[i], dyn=dyn, scale=c.head_dim ** -0.5, kv_len_max=S + tau + bs,
+                           ws=ws["attn_ws"], max_splits=self.max_splits, out_frag=ws["attn_frag"])
+            ops.gemm_resid(lw["o"], src["attn"], H, c.q_dim, ws["h"], add_residual=True, ss_out=ws["ss_h"], dyn=dyn)
+            ops.gemm_silu_mul(lw["gu"], src["ln2"][i], I, H, ws["act_frag"], dyn)
+            ops.gemm_resid(lw["down"], src["act"], H, I, ws["h"], add_residual=True, ss_out=ws["ss_h"], dyn=dyn)
         if append:
             cache.length = S + tau
-        return ws["xn_frag"]
+        return src["final"]
 
     def draft_tokens(self, hid_frag: torch.Tensor, lm_head_wp: torch.Tensor, bs: int, block_ids: torch.Tensor,
                      logits: Optional[torch.Tensor] = None) -> None:
@@ -318,8 +328,11 @@ class DFlashDraftModel:
         frag = self.draft_block(cache, th_rows=th[head:].contiguous() if tau else None, tau=tau, bs=q_len,
                                 pos0=pos0 + head, noise=noise_embedding[0].to(BF16).contiguous())
         cache.length += q_len  # the reference's cache holds the block rows until crop()
-        H = c.hidden_size
-        return frag.view(H // 8, 16, 8).permute(1, 0, 2).reshape(16, H)[:q_len].unsqueeze(0).clone()
+        del frag
+        H, ws = c.hidden_size, self._workspace()
+        ops.norm_pack(norm_w=self.w["norm"], frag=ws["xn_frag"], H=H, eps=c.rms_norm_eps, resid_in=ws["h"],
+                      dyn=cache.dyn, dyn_word=ops.DYN_BS)
+        return ws["xn_frag"].view(H // 8, 16, 8).permute(1, 0, 2).reshape(16, H)[:q_len].unsqueeze(0).clone()
 
     __call__ = forward
 

@@ -9,7 +9,7 @@ from typing import Optional
 
 import torch
 
-from ._lib import check, lib
+from ._lib import Rows, check, lib
 
 BF16, F32, I32, I64 = torch.bfloat16, torch.float32, torch.int32, torch.int64
 DYN_S, DYN_TAU, DYN_BS, DYN_POS0, DYN_START, DYN_STOP, DYN_CYCLE = range(7)
@@ -63,10 +63,52 @@ def pack_rows(x: torch.Tensor, rows: int, out_frag: torch.Tensor, dyn=None, dyn_
                               _p(dyn, I32, "dyn"), dyn_word, _stream()), "dfl_pack_rows")
 
 
-def gemm_f32(wp, xf0, xf1, mt: int, N: int, K: int, ksplit: int, out: torch.Tensor) -> None:
+# ---- row sources (dfl_rows): where a GEMM's 16-row activation tile comes from ---------
+import ctypes as _C
+
+
+class RowSource:
+    """Keeps the ctypes struct and the tensors it points into alive together."""
+
+    def __init__(self, struct: Rows, *keep):
+        self.struct, self.keep = struct, keep
+
+    @property
+    def ref(self):
+        return _C.byref(self.struct)
+
+
+def rows_frag(frag: torch.Tensor) -> RowSource:
+    """frag16 fragments written by a producer kernel."""
+    return RowSource(Rows(_p(frag, BF16, "frag"), None, 0, None, 0, None, 0.0, -1, 0), frag)
+
+
+def rows_plain(rows: torch.Tensor, valid_word: int = -1) -> RowSource:
+    """bf16 rows [<=16, K] (unit inner stride); rows >= dyn[valid_word] count as zero.
+    The buffer must hold 16 readable rows."""
+    assert rows.is_cuda and rows.dtype == BF16 and rows.dim() == 2 and rows.stride(1) == 1
+    return RowSource(Rows(None, rows.data_ptr(), rows.stride(0), None, 0, None, 0.0, valid_word, 1), rows)
+
+
+def rows_normed(rows: torch.Tensor, ss: torch.Tensor, nss: int, norm_w: torch.Tensor, eps: float,
+                valid_word: int = -1) -> RowSource:
+    """the residual stream + partial sums of squares: the GEMM applies the RMSNorm itself."""
+    assert rows.is_cuda and rows.dtype == BF16 and rows.dim() == 2 and rows.stride(1) == 1
+    assert ss.numel() >= nss * 16
+    return RowSource(Rows(None, rows.data_ptr(), rows.stride(0), _p(ss, F32, "ss"), nss, _p(norm_w, BF16, "norm_w"),
+                          eps, valid_word, 2), rows, ss, norm_w)
+
+
+def _src(x) -> RowSource:
+    return x if isinstance(x, RowSource) else rows_frag(x)
+
+
+def gemm_f32(wp, x0, x1, mt: int, N: int, K: int, ksplit: int, out: torch.Tensor, dyn=None) -> None:
+    """x0/x1: RowSource, or a frag16 tensor."""
     assert out.numel() >= ksplit * mt * 16 * N
-    check(lib().dfl_gemm_f32(_p(wp, BF16, "wp"), _p(xf0, BF16, "xf0"), _p(xf1, BF16, "xf1"), mt, N, K, ksplit,
-                             _p(out, F32, "out"), _stream()), "dfl_gemm_f32")
+    s0, s1 = _src(x0), (_src(x1) if x1 is not None else None)
+    check(lib().dfl_gemm_f32(_p(wp, BF16, "wp"), s0.ref, s1.ref if s1 is not None else None, mt, N, K, ksplit,
+                             _p(out, F32, "out"), _p(dyn, I32, "dyn"), _stream()), "dfl_gemm_f32")
 
 
 def min_ksplit(K: int, mt: int) -> int:
@@ -95,23 +137,44 @@ def pick_ksplit(N: int, K: int, mt: int) -> int:
     return best
 
 
-def gemm_silu_mul(wp_gu, xf, I: int, K: int, act_frag: torch.Tensor) -> None:
+def gemm_silu_mul(wp_gu, x, I: int, K: int, act_frag: torch.Tensor, dyn=None) -> None:
     assert act_frag.numel() >= 16 * I
-    check(lib().dfl_gemm_silu_mul(_p(wp_gu, BF16, "wp_gu"), _p(xf, BF16, "xf"), I, K, _p(act_frag, BF16, "act"),
-                                  _stream()), "dfl_gemm_silu_mul")
+    check(lib().dfl_gemm_silu_mul(_p(wp_gu, BF16, "wp_gu"), _src(x).ref, I, K, _p(act_frag, BF16, "act"),
+                                  _p(dyn, I32, "dyn"), _stream()), "dfl_gemm_silu_mul")
 
 
 def argmax_ws(device) -> torch.Tensor:
     return torch.empty(lib().dfl_argmax_ws_bytes(), dtype=torch.uint8, device=device)
 
 
-def gemm_argmax(wp, xf, V: int, K: int, row0: int, nrows: int, ws, out_ids: torch.Tensor, out_off: int = 0,
+def gemm_argmax(wp, x, V: int, K: int, row0: int, nrows: int, ws, out_ids: torch.Tensor, out_off: int = 0,
                 dyn=None, nrows_dyn_word: int = -1, logits: Optional[torch.Tensor] = None) -> None:
     if logits is not None:
         assert logits.numel() >= 16 * V
-    check(lib().dfl_gemm_argmax(_p(wp, BF16, "wp"), _p(xf, BF16, "xf"), V, K, row0, nrows, _p(dyn, I32, "dyn"),
+    check(lib().dfl_gemm_argmax(_p(wp, BF16, "wp"), _src(x).ref, V, K, row0, nrows, _p(dyn, I32, "dyn"),
                                 nrows_dyn_word, _p(ws), _p(out_ids, I64, "out_ids"), out_off,
                                 _p(logits, BF16, "logits"), _stream()), "dfl_gemm_argmax")
+
+
+def gemm_resid(wp, x, N: int, K: int, h_io: torch.Tensor, *, add_residual: bool, ss_out=None, tap=None,
+               dyn=None) -> None:
+    """h_io [16, >=N] bf16 (unit inner stride) updated in place; tap: optional [16, *] view
+    receiving the same rows; ss_out: fp32 [N/16 * 16] partial sums of squares."""
+    assert h_io.is_cuda and h_io.dtype == BF16 and h_io.stride(1) == 1
+    tp, ldt = None, 0
+    if tap is not None:
+        assert tap.is_cuda and tap.dtype == BF16 and tap.stride(1) == 1
+        tp, ldt = tap.data_ptr(), tap.stride(0)
+    if ss_out is not None:
+        assert ss_out.numel() >= N
+    check(lib().dfl_gemm_resid(_p(wp, BF16, "wp"), _src(x).ref, N, K, h_io.data_ptr(), h_io.stride(0),
+                               int(add_residual), tp, ldt, _p(ss_out, F32, "ss_out"), _p(dyn, I32, "dyn"), _stream()),
+          "dfl_gemm_resid")
+
+
+def embed_rows(embed, ids, h_out, H: int, ss_out, dyn=None, dyn_word: int = 0) -> None:
+    check(lib().dfl_embed_rows(_p(embed, BF16, "embed"), _p(ids, I64, "ids"), _p(h_out, BF16, "h_out"), H,
+                               _p(ss_out, F32, "ss_out"), _p(dyn, I32, "dyn"), dyn_word, _stream()), "dfl_embed_rows")
 
 
 def norm_pack(*, norm_w, frag, H: int, eps: float, part=None, nsplit=0, part_split=0, ldp=0, row_off=0,

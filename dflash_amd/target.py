@@ -111,10 +111,19 @@ class NativeTarget:
         self.ks_down = ops.pick_ksplit(self.H, self.I, 1)
         npart = max(self.ks_qkv * 16 * self.nqkv, self.ks_o * 16 * self.H, self.ks_down * 16 * self.H)
         z = lambda *s, dt=BF16: torch.zeros(*s, dtype=dt, device=dev)  # noqa: E731
-        self.ws = dict(xn=z(16 * self.H), attn=z(16 * self.q_dim), act=z(16 * self.I), h=z(16, self.H),
+        self.ws = dict(attn=z(16 * self.q_dim), act=z(16 * self.I), h=z(16, self.H),
+                       ss_emb=z(16, dt=torch.float32), ss_h=z(self.H, dt=torch.float32),
                        q=z(self.n_q, 16, 128), part=z(npart, dt=torch.float32),
                        attn_ws=ops.attn_fused_ws(self.n_q, self.n_kv, max_splits, dev), argmax_ws=ops.argmax_ws(dev),
                        post=torch.zeros(16, dtype=torch.int64, device=dev))
+        ws, nt = self.ws, self.H // 16
+        # row sources: the consuming GEMM applies the RMSNorm itself (no norm launches)
+        self.src = dict(
+            ln1=[ops.rows_normed(ws["h"], ws["ss_emb"] if i == 0 else ws["ss_h"], 1 if i == 0 else nt, lw["ln1"],
+                                 self.eps, ops.DYN_BS) for i, lw in enumerate(self.layers)],
+            ln2=[ops.rows_normed(ws["h"], ws["ss_h"], nt, lw["ln2"], self.eps, ops.DYN_BS) for lw in self.layers],
+            final=ops.rows_normed(ws["h"], ws["ss_h"], nt, self.norm, self.eps, ops.DYN_BS),
+            attn=ops.rows_frag(ws["attn"]), act=ops.rows_frag(ws["act"]))
         self._rope = None
         self._taps = {}
         torch.cuda.synchronize(dev)
@@ -185,38 +194,31 @@ class NativeTarget:
             if key not in self._taps:
                 self._taps[key] = torch.zeros(16, key * H, dtype=BF16, device=self._dev)
             taps = self._taps[key]
-        ld2 = len(tap_layers) * H
-        Ls = self.layers
-        ops.norm_pack(norm_w=Ls[0]["ln1"], frag=ws["xn"], H=H, eps=self.eps, embed=self.embed, ids=block_ids,
-                      h_out=ws["h"], dyn=dyn, dyn_word=ops.DYN_BS)
+        Ls, src = self.layers, self.src
+        ops.embed_rows(self.embed, block_ids, ws["h"], H, ws["ss_emb"], dyn, ops.DYN_BS)
         for i, lw in enumerate(Ls):
-            ops.gemm_f32(lw["qkv"], ws["xn"], None, 1, self.nqkv, H, self.ks_qkv, ws["part"])
-            layout = dict(qkv=ws["part"], nsplit=self.ks_qkv, split_stride=16 * self.nqkv, ld=self.nqkv, q_col=0,
-                          k_col=self.q_dim, v_col=self.q_dim + self.kv_dim, ctx_row0=0, blk_row0=0, n_q=self.n_q,
-                          n_kv=self.n_kv, q_norm_w=lw["q_norm"], k_norm_w=lw["k_norm"], eps=self.eps, cos_tab=cos,
-                          sin_tab=sin, kcache=cache.k[i], vcache=cache.v[i], dyn=dyn)
-            ops.attn_fused(**layout, scale=128 ** -0.5, kv_len_max=start + bs, ws=ws["attn_ws"],
-                           max_splits=self.max_splits, out_frag=ws["attn"], causal=True)
-            ops.gemm_f32(lw["o"], ws["attn"], None, 1, H, self.q_dim, self.ks_o, ws["part"])
-            ops.norm_pack(norm_w=lw["ln2"], frag=ws["xn"], H=H, eps=self.eps, part=ws["part"], nsplit=self.ks_o,
-                          part_split=16 * H, ldp=H, resid_in=ws["h"], h_out=ws["h"], dyn=dyn, dyn_word=ops.DYN_BS)
-            ops.gemm_silu_mul(lw["gu"], ws["xn"], self.I, H, ws["act"])
-            ops.gemm_f32(lw["down"], ws["act"], None, 1, H, self.I, self.ks_down, ws["part"])
-            nxt = Ls[i + 1]["ln1"] if i + 1 < self.L else self.norm
-            h2 = None
-            if i in tap_layers:
-                j = tap_layers.index(i)
-                h2 = taps[:, j * H:(j + 1) * H]
-            ops.norm_pack(norm_w=nxt, frag=ws["xn"], H=H, eps=self.eps, part=ws["part"], nsplit=self.ks_down,
-                          part_split=16 * H, ldp=H, resid_in=ws["h"], h_out=ws["h"], h_out2=h2, ld2=ld2, dyn=dyn,
-                          dyn_word=ops.DYN_BS)
+            ops.gemm_f32(lw["qkv"], src["ln1"][i], None, 1, self.nqkv, H, self.ks_qkv, ws["part"], dyn)
+            ops.attn_fused(qkv=ws["part"], nsplit=self.ks_qkv, split_stride=16 * self.nqkv, ld=self.nqkv, q_col=0,
+                           k_col=self.q_dim, v_col=self.q_dim + self.kv_dim, ctx_row0=0, blk_row0=0, n_q=self.n_q,
+                           n_kv=self.n_kv, q_norm_w=lw["q_norm"], k_norm_w=lw["k_norm"], eps=self.eps, cos_tab=cos,
+                           sin_tab=sin, kcache=cache.k[i], vcache=cache.v[i], dyn=dyn, scale=128 ** -0.5,
+                           kv_len_max=start + bs, ws=ws["attn_ws"], max_splits=self.max_splits, out_frag=ws["attn"],
+                           causal=True)
+            ops.gemm_resid(lw["o"], src["attn"], H, self.q_dim, ws["h"], add_residual=True, ss_out=ws["ss_h"],
+                           dyn=dyn)
+            ops.gemm_silu_mul(lw["gu"], src["ln2"][i], self.I, H, ws["act"], dyn)
+            tap = taps[:, tap_layers.index(i) * H:(tap_layers.index(i) + 1) * H] if i in tap_layers else None
+            ops.gemm_resid(lw["down"], src["act"], H, self.I, ws["h"], add_residual=True, ss_out=ws["ss_h"], tap=tap,
+                           dyn=dyn)
         post = ws["post"]
         if temperature < 1e-5:
-            ops.gemm_argmax(self.lm_wp, ws["xn"], self.V, H, 0, bs, ws["argmax_ws"], post, 0, logits=logits_out)
+            ops.gemm_argmax(self.lm_wp, src["final"], self.V, H, 0, bs, ws["argmax_ws"], post, 0, dyn=dyn,
+                            logits=logits_out)
             posterior = post[:bs].unsqueeze(0)
         else:
             logits = torch.empty(16, self.V, dtype=BF16, device=self._dev)
-            ops.gemm_argmax(self.lm_wp, ws["xn"], self.V, H, 0, bs, ws["argmax_ws"], post, 0, logits=logits)
+            ops.gemm_argmax(self.lm_wp, src["final"], self.V, H, 0, bs, ws["argmax_ws"], post, 0, dyn=dyn,
+                            logits=logits)
             posterior = sample(logits[:bs].unsqueeze(0), temperature)
         cache.length = start + bs
         return posterior, taps

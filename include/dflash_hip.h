@@ -54,6 +54,27 @@ extern "C" {
 #define DFL_DYN_STOP 5     /* 1 once a stop token was committed                 */
 #define DFL_DYN_CYCLE 6    /* cycles run                                        */
 
+/* Where one 16-row activation tile of a GEMM comes from.
+ *  mode 0  frag   : frag16 fragments [K/8][16][8] written by a producer kernel;
+ *  mode 1  rows   : plain bf16 rows [16][K] with row stride ld (e.g. the target taps);
+ *  mode 2  normed : rows = the residual stream h, and the GEMM applies the RMSNorm while
+ *                   it builds its fragments: x = norm_w * bf16(h * rsqrt(sum_i ss[i][m] / K
+ *                   + eps)) (Qwen3RMSNorm, tf:models/qwen3/modeling_qwen3.py:59-64), where
+ *                   ss[nss][16] are partial sums of squares of each row left by the
+ *                   producer (dfl_embed_rows: nss = 1; dfl_gemm_resid: nss = N/16).
+ * Rows >= dyn[valid_word] (valid_word >= 0) are treated as zero. */
+typedef struct dfl_rows {
+  const void *frag;
+  const void *rows;
+  int64_t ld;
+  const float *ss;
+  int32_t nss;
+  const void *norm_w;
+  float eps;
+  int32_t valid_word;
+  int32_t mode;
+} dfl_rows;
+
 int dfl_version(void);
 const char *dfl_last_error(void);
 
@@ -80,16 +101,17 @@ int dfl_pack_rows(const void *x, int64_t ldx, int rows, int K, void *xf, const i
 /* Skinny GEMM, weights streamed once: out[c][mt*16+m][n] = sum_{k in chunk c} x_mt[m][k] * W[n][k]
  * (fp32 partials, summed and rounded to bf16 by the consumer exactly where the
  * reference's nn.Linear output is rounded).  Replaces F.linear at model/dflash.py:70,
- * 73-76,101,177 and the down_proj of tf:...modeling_qwen3.py:82.
- * mt in {1,2} row tiles (xf1 ignored for mt==1), N%16==0, K%32==0,
- * out has ksplit*mt*16*N floats; ksplit >= ceil(K/32 / (16*8/mt)). */
-int dfl_gemm_f32(const void *wp, const void *xf0, const void *xf1, int mt, int N, int K, int ksplit, float *out,
-                 void *stream);
+ * 73-76 (q/k/v of context and block rows).  mt in {1,2} row tiles (x1 ignored for
+ * mt==1), N%16==0, K%32==0, out has ksplit*mt*16*N floats;
+ * ksplit >= ceil(K/32 / (16*8/mt)). */
+int dfl_gemm_f32(const void *wp, const dfl_rows *x0, const dfl_rows *x1, int mt, int N, int K, int ksplit, float *out,
+                 const int32_t *dyn, void *stream);
 
 /* act = bf16(silu(bf16(x Wg^T))) * bf16(x Wu^T) written as frag16 [I/8][16][8]
  * (tf:...modeling_qwen3.py:82 inner expression).  wp from dfl_pack_weight_gateup.
  * K/32 <= 128 (no K split: the activation needs the finished sums). */
-int dfl_gemm_silu_mul(const void *wp_gateup, const void *xf, int I, int K, void *act_frag, void *stream);
+int dfl_gemm_silu_mul(const void *wp_gateup, const dfl_rows *x, int I, int K, void *act_frag, const int32_t *dyn,
+                      void *stream);
 
 /* lm_head GEMM fused with the greedy unmask: ids[r] = argmax_n bf16(x[r] . W[n])
  * for r in [row0, row0+nrows), first index on ties (model/dflash.py:238-247 +
@@ -98,8 +120,22 @@ int dfl_gemm_silu_mul(const void *wp_gateup, const void *xf, int I, int K, void 
  * ws: workspace of dfl_argmax_ws_bytes() bytes.  out_ids int64, written at
  * out_ids[r - row0 + out_off]. nrows_dyn_word >= 0: rows = dyn[word] - row0. */
 int64_t dfl_argmax_ws_bytes(void);
-int dfl_gemm_argmax(const void *wp, const void *xf, int V, int K, int row0, int nrows, const int32_t *dyn,
+int dfl_gemm_argmax(const void *wp, const dfl_rows *x, int V, int K, int row0, int nrows, const int32_t *dyn,
                     int nrows_dyn_word, void *ws, int64_t *out_ids, int out_off, void *logits, void *stream);
+
+/* GEMM with the residual epilogue (o_proj / down_proj / fc, model/dflash.py:101,140,144,177):
+ *   v = bf16(x W^T);  h_io[m][n] <- add_residual ? bf16(h_io[m][n] + v) : v;
+ *   tap[m][n] <- the same value (optional: a tapped target layer, model/utils.py:16-25);
+ *   ss_out[n/16][m] <- sum over the tile's 16 columns of h_new^2 (optional; feeds the
+ *   mode-2 row source of the next GEMM, so the RMSNorm is no launch of its own).
+ * Any K: beyond 4096 the workgroup walks K in chunks itself (x must then be mode 0/1). */
+int dfl_gemm_resid(const void *wp, const dfl_rows *x, int N, int K, void *h_io, int64_t ldh, int add_residual,
+                   void *tap, int64_t ldtap, float *ss_out, const int32_t *dyn, void *stream);
+
+/* h_out[m] = embed[ids[m]] for m < dyn[dyn_word] (model/dflash.py:237) and ss_out[m] =
+ * sum of squares of that row (one partial per row: nss = 1 for the next GEMM). */
+int dfl_embed_rows(const void *embed, const int64_t *ids, void *h_out, int H, float *ss_out, const int32_t *dyn,
+                   int dyn_word, void *stream);
 
 /* Row-wise residual/norm stage that also converts to frag16:
  *   v   = part ? bf16(sum_c part[c][row_off+m][:]) : (none)

@@ -29,7 +29,7 @@ def test_argument_validation_needs_no_gpu():
     h = _lib.lib()
     assert h.dfl_pack_weight(None, None, 16, 32, None) == -22
     assert b"null" in h.dfl_last_error()
-    assert h.dfl_gemm_f32(1, 1, None, 3, 16, 32, 1, 1, None) == -22
+    assert h.dfl_gemm_f32(1, None, None, 3, 16, 32, 1, 1, None, None) == -22
     assert h.dfl_accept_commit(1, 1, 0, 1, 4, 1, None, 0, None, None) == -22
 
 

@@ -154,6 +154,68 @@ def test_gemm_argmax_forced_tie(ops):
     assert (ids == 0).all()
 
 
+def test_gemm_row_sources_and_resid_epilogue(ops):
+    """The fused residual/norm pipeline: embed_rows -> GEMM reading (h, ss) with the
+    RMSNorm applied in its prologue -> GEMM with the residual epilogue (h, taps, new ss),
+    against the oracle's rms_norm + plain fp32 matmuls.  Also the K-chunked form."""
+    from oracle.dflash_oracle import rms_norm
+    Hd, I, V, bs = 1024, 12288 // 4, 512, 11
+    g = gen(21)
+    emb = (torch.randn(V, Hd, generator=g) * 0.7).to(BF16)
+    ids = torch.randint(0, V, (16,), generator=g)
+    nw = (1 + 0.1 * torch.randn(Hd, generator=g)).to(BF16)
+    w1 = (torch.randn(I, Hd, generator=g) * 0.03).to(BF16)      # consumes norm(h)
+    w2 = (torch.randn(Hd, I, generator=g) * 0.03).to(BF16)      # K = 3072 > 128 k-steps x ... chunked path? (3072/32=96: single pass)
+    w3 = (torch.randn(Hd, 20480 // 4, generator=g) * 0.02).to(BF16)  # K = 5120 -> 160 k-steps: chunked
+    dyn = torch.zeros(8, dtype=torch.int32, device=dev())
+    ops.set_dyn(dyn, 0, 7, bs, 0)
+    h = torch.zeros(16, Hd, dtype=BF16, device=dev())
+    ss0 = torch.zeros(16, device=dev())
+    ops.embed_rows(emb.to(dev()), ids.to(dev()), h, Hd, ss0, dyn, ops.DYN_BS)
+    assert torch.equal(h[:bs].cpu(), emb[ids][:bs]) and torch.count_nonzero(h[bs:]) == 0
+    assert torch.allclose(ss0[:bs].cpu(), emb[ids][:bs].float().pow(2).sum(-1), rtol=1e-5)
+    # GEMM with the norm in its prologue == GEMM on oracle-normalised rows
+    out = torch.zeros(1, 16, I, device=dev())
+    ops.gemm_f32(ops.pack_weight(w1.to(dev())), ops.rows_normed(h, ss0, 1, nw.to(dev()), 1e-6, ops.DYN_BS), None, 1, I, Hd,
+                 1, out, dyn)
+    xn = rms_norm(emb[ids], nw, 1e-6)
+    ref = xn.float() @ w1.float().t()
+    d = (out[0, :bs].cpu() - ref[:bs]).abs()
+    assert d.max() <= 2e-2 * ref.abs().max() and d.mean() <= 1e-3 * ref.abs().max()   # 1-ulp flips of normed inputs
+    assert torch.count_nonzero(out[0, bs:]) == 0                                        # rows >= valid are zero
+    # residual epilogue, single pass (K = 3072)
+    act = (torch.randn(16, I, generator=g) * 0.5).to(BF16)
+    act_frag = to_frag(ops, act.to(dev()))
+    taps = torch.zeros(16, 3 * Hd, dtype=BF16, device=dev())
+    ss1 = torch.zeros(Hd, device=dev())
+    h0 = h.clone()
+    ops.gemm_resid(ops.pack_weight(w2.to(dev())), act_frag, Hd, I, h, add_residual=True, ss_out=ss1,
+                   tap=taps[:, Hd:2 * Hd], dyn=dyn)
+    lin = (act.float() @ w2.float().t()).to(BF16)
+    h_ref = (h0.cpu() + lin)
+    dd = (h.cpu().float() - h_ref.float()).abs()
+    assert dd.max() <= 2 ** -6 * h_ref.float().abs().max() and (dd > 0).float().mean() < 0.02
+    assert torch.equal(taps[:, Hd:2 * Hd], h) and torch.count_nonzero(taps[:, :Hd]) == 0
+    ssq = ss1.view(Hd // 16, 16).sum(0).cpu()
+    assert torch.allclose(ssq, h.cpu().float().pow(2).sum(-1), rtol=1e-4)
+    # chunked K (fc-like): plain rows source with 7 valid rows, no residual
+    th = (torch.randn(7, 5120, generator=g)).to(BF16).to(dev())
+    ctxh = torch.full((16, Hd), 7.0, dtype=BF16, device=dev())
+    ssc = torch.zeros(Hd, device=dev())
+    ops.gemm_resid(ops.pack_weight(w3.to(dev())), ops.rows_plain(th, ops.DYN_TAU), Hd, 5120, ctxh, add_residual=False,
+                   ss_out=ssc, dyn=dyn)
+    ref3 = (th.cpu().float() @ w3.float().t()).to(BF16)
+    d3 = (ctxh[:7].cpu().float() - ref3.float()).abs()
+    assert d3.max() <= 2 ** -6 * ref3.float().abs().max() and (d3 > 0).float().mean() < 0.02
+    assert torch.count_nonzero(ctxh[7:]) == 0
+    # exact-integer check of the chunked path (layout / chunk bookkeeping)
+    wi = torch.randint(-2, 3, (64, 4096 * 3), generator=g).to(BF16)
+    xi = torch.randint(-2, 3, (16, 4096 * 3), generator=g).to(BF16)
+    hi = torch.zeros(16, 64, dtype=BF16, device=dev())
+    ops.gemm_resid(ops.pack_weight(wi.to(dev())), to_frag(ops, xi.to(dev())), 64, 4096 * 3, hi, add_residual=False)
+    assert torch.equal(hi.cpu().float(), (xi.float() @ wi.float().t()).to(BF16).float())
+
+
 # ------------------------------------------------------------------ row stages
 def test_norm_pack_variants(ops):
     from oracle.dflash_oracle import rms_norm
