@@ -104,22 +104,12 @@ __global__ __launch_bounds__(1024) void k_gemm(GemmArgs a) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l = tid & 63;
 
-  // ---- row validity and (mode 2) the rows' rstd, once per wave
+  // ---- row validity (rows >= dyn[valid_word] count as zero)
   int nv[MT];
-  float rstd[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    const RowSrc &s = a.src[mt];
-    nv[mt] = (s.valid_word >= 0 && a.dyn) ? a.dyn[s.valid_word] : 16;
-    rstd[mt] = 1.f;
-    if (s.mode == 2) {
-      const int m = l & 15, part = l >> 4;
-      float t = 0.f;
-      for (int i = part; i < s.nss; i += 4) t += s.ss[i * 16 + m];  // fixed order: reproducible
-      t += __shfl_xor(t, 16, 64);
-      t += __shfl_xor(t, 32, 64);
-      rstd[mt] = rsqrtf(t / (float)(a.KS * 32) + s.eps);
-    }
+    const RowSrc &s0 = a.src[mt];
+    nv[mt] = (s0.valid_word >= 0 && a.dyn) ? a.dyn[s0.valid_word] : 16;
   }
 
   auto ks0_of = [&](int c) { return ((blockIdx.y * a.nch + c) * 16 + w) * a.nfr; };
@@ -128,18 +118,7 @@ __global__ __launch_bounds__(1024) void k_gemm(GemmArgs a) {
     return nf < 0 ? 0 : (nf > a.nfr ? a.nfr : nf);
   };
 
-  // activations of the (single) chunk stay in registers for the launch
-  bf16x8 xr[MT][FR];
-  if (!CHUNKED) {
-    const int ks0 = ks0_of(0), nf = nf_of(0);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int f = 0; f < FR; ++f) {
-        const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-        xr[mt][f] = f < nf ? load_x(a.src[mt], ks0 + f, l, nv[mt], rstd[mt]) : z;
-      }
-  }
+  bf16x8 xr[MT][FR];  // activations of the (single) chunk stay in registers for the launch
 
   // ---- tile sequence of this workgroup.  F32/ARGMAX/RESID: tiles bx, bx+G, ...
   // SILU: the packed weight interleaves (gate tile p, up tile p) and the sequence walks
@@ -254,9 +233,63 @@ __global__ __launch_bounds__(1024) void k_gemm(GemmArgs a) {
   bf16x8 wA[FR], wB[FR];
   bf16x8 xA[MT][FR], xB[MT][FR];
   const int nitems = nseq * a.nch;
+  if (nitems > 0) load_item(wA, xA, tile_of(0), 0);  // first weights leave for HBM before the prologue
+
+  // ---- (mode 2) the rows' rstd, computed while the first weights are in flight.  The nss partial sums of squares of a
+  // row are summed by the 16 waves together: wave w takes partials w, w+16, ... with four
+  // unconditional loads in flight per lane (a serial loop over all 256 cost ~20 us of
+  // dependent L2 round trips per launch), then one LDS exchange in a fixed order.
+  __shared__ float ssred[MT][16][16];
+  float rstd[MT];
+  bool any_norm = false;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const RowSrc &s = a.src[mt];
+    rstd[mt] = 1.f;
+    if (s.mode == 2) {
+      any_norm = true;
+      const int m = l & 15, part = l >> 4;
+      float t = 0.f;
+      for (int base = 0; base < s.nss; base += 256) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = base + w + 16 * (part + 4 * u);
+          v[u] = s.ss[(i < s.nss ? i : s.nss - 1) * 16 + m];
+          v[u] = i < s.nss ? v[u] : 0.f;
+        }
+        t += (v[0] + v[1]) + (v[2] + v[3]);
+      }
+      t += __shfl_xor(t, 16, 64);
+      t += __shfl_xor(t, 32, 64);
+      if (part == 0) ssred[mt][w][m] = t;
+    }
+  }
+  if (any_norm) {  // uniform over the workgroup: the modes are kernel arguments
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      if (a.src[mt].mode == 2) {
+        float t = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 16; ++ww) t += ssred[mt][ww][l & 15];
+        rstd[mt] = rsqrtf(t / (float)(a.KS * 32) + a.src[mt].eps);
+      }
+  }
+
+  if (!CHUNKED) {
+    const int ks0 = ks0_of(0), nf = nf_of(0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int f = 0; f < FR; ++f) {
+        const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        xr[mt][f] = f < nf ? load_x(a.src[mt], ks0 + f, l, nv[mt], rstd[mt]) : z;
+      }
+  }
+
   if (nitems > 0) {
     int j = 0, c = 0;  // current item
-    load_item(wA, xA, tile_of(0), 0);
     for (int i = 0;; i += 2) {
       int jn = j, cn = c + 1;  // item i+1
       if (cn == a.nch) {
