@@ -79,19 +79,38 @@ __device__ __forceinline__ float row_sum16(float v) {
   return v;
 }
 
-// B-operand fragment of k-step ks for lane l (m = l&15, kq = l>>4): x[m][ks*32 + kq*8 ..+8]
-__device__ __forceinline__ bf16x8 load_x(const RowSrc &s, int ks, int l, int nv, float rstd) {
+// B-operand fragments of k-steps ks[0..NF) for lane l (m = l&15, kq = l>>4):
+// x[m][ks*32 + kq*8 .. +8].  `take[f]` false -> zero fragment (k-step past the wave's
+// share or past K; ks[f] is then any valid step).  The source mode is switched OUTSIDE the
+// fragment loop so that the loads of one call are issued together; branching per fragment
+// serialised them with a vmcnt(0) each (8 L2 round trips, +6.5 us per launch, measured).
+template <int NF>
+__device__ __forceinline__ void build_x(const RowSrc &s, const int (&ks)[NF], const bool (&take)[NF], int l, int nv,
+                                        float rstd, bf16x8 (&x)[NF]) {
   const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (s.mode == 0) return s.frag[(size_t)ks * 64 + l];
-  const int m = l & 15, k0 = ks * 32 + (l >> 4) * 8;
-  const int mr = m < nv ? m : (nv > 0 ? nv - 1 : 0);  // never read past the caller's valid rows
-  bf16x8 v = *reinterpret_cast<const bf16x8 *>(s.rows + (int64_t)mr * s.ld + k0);
-  if (s.mode == 2) {  // Qwen3RMSNorm: weight * bf16(x * rstd), tf:modeling_qwen3.py:59-64
-    const bf16x8 wv = *reinterpret_cast<const bf16x8 *>(s.nw + k0);
+  if (s.mode == 0) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(wv[j]) * rbf(bf2f(v[j]) * rstd));
+    for (int f = 0; f < NF; ++f) x[f] = s.frag[(size_t)ks[f] * 64 + l];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) x[f] = take[f] ? x[f] : z;
+    return;
   }
-  return m < nv ? v : z;
+  const int m = l & 15, kq = l >> 4;
+  const int mr = m < nv ? m : (nv > 0 ? nv - 1 : 0);  // never read past the caller's valid rows
+  const bf16_t *row = s.rows + (int64_t)mr * s.ld + kq * 8;
+#pragma unroll
+  for (int f = 0; f < NF; ++f) x[f] = *reinterpret_cast<const bf16x8 *>(row + ks[f] * 32);
+  if (s.mode == 2) {  // Qwen3RMSNorm: weight * bf16(x * rstd), tf:modeling_qwen3.py:59-64
+    bf16x8 wv[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) wv[f] = *reinterpret_cast<const bf16x8 *>(s.nw + ks[f] * 32 + kq * 8);
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[f][j] = f2bf(bf2f(wv[f][j]) * rbf(bf2f(x[f][j]) * rstd));
+  }
+#pragma unroll
+  for (int f = 0; f < NF; ++f) x[f] = (take[f] && m < nv) ? x[f] : z;
 }
 
 template <int MT, bool CHUNKED, int EPI>
@@ -146,18 +165,30 @@ __global__ __launch_bounds__(1024) void k_gemm(GemmArgs a) {
     if (a.dyn && a.nrows_word >= 0) arg_rows = a.dyn[a.nrows_word] - a.row0;
   }
 
+  // Guards on the k-step count must be loop-invariant or absent: a per-item runtime guard
+  // makes hipcc branch around every fragment load and wait vmcnt(0) after each (49 full
+  // waits instead of 16 in the SILU kernel, 34 -> 41 us).  Single-chunk kernels use the
+  // wave's fixed nf0; the chunked kernel loads unconditionally from a clamped k-step and
+  // feeds zero activations past the end of K (finite weight x 0 = 0).
+  const int nf0 = nf_of(0);
   auto load_item = [&](bf16x8(&wr)[FR], bf16x8(&xb)[MT][FR], int t, int c) {
-    const int ks0 = ks0_of(c), nf = nf_of(c);
-    const bf16x8 *base = a.wp + ((size_t)t * a.KS + ks0) * 64 + l;
+    if (!CHUNKED) {
+      const bf16x8 *base = a.wp + ((size_t)t * a.KS + ks0_of(0)) * 64 + l;
 #pragma unroll
-    for (int f = 0; f < FR; ++f)
-      if (f < nf) wr[f] = ld_stream(base + (size_t)f * 64);
-    if (CHUNKED) {
+      for (int f = 0; f < FR; ++f)
+        if (f < nf0) wr[f] = ld_stream(base + (size_t)f * 64);
+    } else {
+      const int ks0 = ks0_of(c);
+      int ks[FR];
+      bool take[FR];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+      for (int f = 0; f < FR; ++f) {
+        take[f] = ks0 + f < a.KS;
+        ks[f] = take[f] ? ks0 + f : a.KS - 1;
+        wr[f] = ld_stream(a.wp + ((size_t)t * a.KS + ks[f]) * 64 + l);
+      }
 #pragma unroll
-        for (int f = 0; f < FR; ++f)
-          if (f < nf) xb[mt][f] = load_x(a.src[mt], ks0 + f, l, nv[mt], 1.f);
+      for (int mt = 0; mt < MT; ++mt) build_x<FR>(a.src[mt], ks, take, l, nv[mt], 1.f, xb[mt]);
     }
   };
 
@@ -214,19 +245,18 @@ __global__ __launch_bounds__(1024) void k_gemm(GemmArgs a) {
   };
 
   auto process = [&](bf16x8(&wr)[FR], bf16x8(&xb)[MT][FR], int t, int c, int pos) {
-    const int nf = nf_of(c);
-    if (c == 0) {
+    if (!CHUNKED || c == 0) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int f = 0; f < FR; ++f)
-      if (f < nf) {
+      if (CHUNKED || f < nf0) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
           acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[f], CHUNKED ? xb[mt][f] : xr[mt][f], acc[mt], 0, 0, 0);
       }
-    if (c == a.nch - 1) finish(t, pos);
+    if (!CHUNKED || c == a.nch - 1) finish(t, pos);
   };
 
   // items (position j in the sequence, chunk c), weights double-buffered A/B
@@ -278,14 +308,15 @@ __global__ __launch_bounds__(1024) void k_gemm(GemmArgs a) {
   }
 
   if (!CHUNKED) {
-    const int ks0 = ks0_of(0), nf = nf_of(0);
+    int ks[FR];
+    bool take[FR];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int f = 0; f < FR; ++f) {
+      take[f] = f < nf0;
+      ks[f] = take[f] ? ks0_of(0) + f : 0;
+    }
 #pragma unroll
-      for (int f = 0; f < FR; ++f) {
-        const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-        xr[mt][f] = f < nf ? load_x(a.src[mt], ks0 + f, l, nv[mt], rstd[mt]) : z;
-      }
+    for (int mt = 0; mt < MT; ++mt) build_x<FR>(a.src[mt], ks, take, l, nv[mt], rstd[mt], xr[mt]);
   }
 
   if (nitems > 0) {

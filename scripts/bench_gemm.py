@@ -60,4 +60,16 @@ if __name__ == "__main__":
         x = torch.randn(16 * K, device=dev).to(BF16)
         act = torch.empty(16 * I, device=dev, dtype=BF16)
         us = time_launches(lambda i: ops.gemm_silu_mul(wps[i], x, I, K, act), n_buf)
-        print(f"silu     I={I} K={K}: {us:8.1f} us  {2 * I * K * 2 / us / 1e6:7.2f} TB/s")
+        print(f"silu     I={I} K={K} frag source  : {us:8.1f} us  {2 * I * K * 2 / us / 1e6:7.2f} TB/s")
+        h = torch.randn(16, K, device=dev).to(BF16)
+        nw = torch.ones(K, device=dev, dtype=BF16)
+        dyn = torch.zeros(8, dtype=torch.int32, device=dev)
+        ops.set_dyn(dyn, 0, 0, 16, 0)
+        for nss in (1, 256):
+            ss = torch.rand(nss * 16, device=dev) * (K / nss)
+            src = ops.rows_normed(h, ss, nss, nw, 1e-6, ops.DYN_BS)
+            us = time_launches(lambda i: ops.gemm_silu_mul(wps[i], src, I, K, act, dyn), n_buf)
+            print(f"silu     I={I} K={K} normed nss={nss:3d}: {us:8.1f} us  {2 * I * K * 2 / us / 1e6:7.2f} TB/s")
+        srcp = ops.rows_plain(h, ops.DYN_BS)
+        us = time_launches(lambda i: ops.gemm_silu_mul(wps[i], srcp, I, K, act, dyn), n_buf)
+        print(f"silu     I={I} K={K} plain rows   : {us:8.1f} us  {2 * I * K * 2 / us / 1e6:7.2f} TB/s")
