@@ -334,3 +334,42 @@ def test_from_pretrained_checkpoint_dir(tmp_path):
     for la, lb in zip(a.w["layers"], b.w["layers"]):
         for k in la:
             assert torch.equal(la[k], lb[k]), k
+
+
+def test_native_target_llama_style():
+    """BASELINE config 4's target family (Llama: no per-head q/k norm, rope_type default
+    here): NativeTarget verify vs the HF forward."""
+    tf = pytest.importorskip("transformers")
+    from transformers import DynamicCache
+    from dflash_amd import NativeTarget
+    cfg = tf.LlamaConfig(vocab_size=2048, hidden_size=512, intermediate_size=1024, num_hidden_layers=4,
+                         num_attention_heads=4, num_key_value_heads=2, head_dim=128, rms_norm_eps=1e-5,
+                         max_position_embeddings=4096, tie_word_embeddings=False, attention_bias=False,
+                         mlp_bias=False, rope_parameters={"rope_type": "default", "rope_theta": 500000.0})
+    cfg._attn_implementation = "sdpa"
+    torch.manual_seed(3)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(BF16)
+    try:
+        with torch.device(dev()):
+            hf = tf.LlamaForCausalLM(cfg).eval()
+    finally:
+        torch.set_default_dtype(prev)
+    nt = NativeTarget(hf)
+    assert nt.layers[0]["q_norm"] is None
+    g = torch.Generator().manual_seed(8)
+    prompt = torch.randint(0, 2000, (1, 29), generator=g).to(dev())
+    block = torch.randint(0, 2000, (1, 12), generator=g).to(dev())
+    cache = nt.new_cache(64)
+    nt.prefill(prompt, cache)
+    logits = torch.zeros(16, 2048, dtype=BF16, device=dev())
+    post, taps = nt.verify(block[0], 29, cache, tap_layers=[1], logits_out=logits)
+    rc = DynamicCache()
+    hf(prompt, past_key_values=rc, use_cache=True)
+    ref = hf(block, position_ids=torch.arange(29, 41, device=dev())[None], past_key_values=rc, use_cache=True,
+             output_hidden_states=True)
+    rl = ref.logits[0].float()
+    assert (logits[:12].float() - rl).abs().max() <= 4e-2 * rl.abs().max()
+    r = ref.hidden_states[2][0].float()
+    assert (taps[:12, :512].float() - r).abs().max() <= 4e-2 * r.abs().max()
+    assert torch.equal(post[0], torch.argmax(logits[:12], dim=-1))
