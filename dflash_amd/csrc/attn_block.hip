@@ -315,50 +315,76 @@ struct FusedAttnArgs {
   int *tickets;    // [n_kv], zero before the first launch; the merger leaves it zero
 };
 
-// NI (row, head) items of 128 values at once on one wave; lane owns d = l and l + 64.
-// brow[i] < 0 marks an absent item (its outputs are garbage, never stored).  rope[i]:
-// per-head norm (if nw) + RoPE; else the plain bf16-rounded copy (V rows).
-// All loads are unconditional: a runtime branch around a load makes hipcc wait vmcnt(0)
-// per element (guide §5 trap c) — measured 50 us per launch when they were guarded.
-template <int NI>
-__device__ __forceinline__ void rope_items(const FusedAttnArgs &a, const int (&brow)[NI], const int (&col)[NI],
-                                           const int (&pos)[NI], const bool (&rope)[NI], const bf16_t *nw, int l,
-                                           float (&o1)[NI], float (&o2)[NI]) {
-  float x1[NI], x2[NI], cs[NI], sn[NI];
-  const float *rp[NI];
+// NP passes of 4 (row, head) items each on one wave: the 16 lanes of a DPP row share an
+// item, lane c = l&15 owns d = 8c .. 8c+7 (c < 8: first half of the head, c >= 8: second
+// half; rotate_half pairs lane c with lane c^8 of the same row).  Per pass a lane issues
+// 2*nsplit 16-B loads of partial sums plus three 16-B table loads, the sum of squares is a
+// 4-step DPP row reduction and the partner values arrive by row_ror:8 — ~5x fewer
+// instructions than one item per wave with lane = d (6 us -> measured below).
+// brow < 0 marks an absent item (loads are clamped, outputs garbage, never stored).
+template <int NP>
+__device__ __forceinline__ void rope_rows(const FusedAttnArgs &a, const int (&brow)[NP], const int (&col)[NP],
+                                          const int (&pos)[NP], const bool (&rope)[NP], const bf16_t *nw, int l,
+                                          bf16x8 (&out)[NP]) {
+  const int c = l & 15, d0 = c * 8;
+  float x[NP][8];
+  bf16x8 cs[NP], sn[NP];
+  const float *rp[NP];
 #pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    x1[i] = 0.f;
-    x2[i] = 0.f;
-    rp[i] = a.qkv + (int64_t)(brow[i] < 0 ? 0 : brow[i]) * a.ld + col[i] + l;
-    int pp = pos[i] < a.max_pos ? pos[i] : a.max_pos - 1;
+  for (int p = 0; p < NP; ++p) {
+    rp[p] = a.qkv + (int64_t)(brow[p] < 0 ? 0 : brow[p]) * a.ld + col[p] + d0;
+    int pp = pos[p] < a.max_pos ? pos[p] : a.max_pos - 1;
     pp = pp < 0 ? 0 : pp;
-    cs[i] = bf2f(a.cos_tab[(int64_t)pp * 64 + l]);
-    sn[i] = bf2f(a.sin_tab[(int64_t)pp * 64 + l]);
+    cs[p] = *reinterpret_cast<const bf16x8 *>(a.cos_tab + (int64_t)pp * 64 + (d0 & 63));
+    sn[p] = *reinterpret_cast<const bf16x8 *>(a.sin_tab + (int64_t)pp * 64 + (d0 & 63));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[p][j] = 0.f;
   }
+  bf16x8 wv = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (nw) wv = *reinterpret_cast<const bf16x8 *>(nw + d0);
   for (int s = 0; s < a.nsplit_k; ++s) {
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      x1[i] += rp[i][s * a.split_stride];
-      x2[i] += rp[i][s * a.split_stride + 64];
+    for (int p = 0; p < NP; ++p) {
+      const f32x4 v0 = *reinterpret_cast<const f32x4 *>(rp[p] + s * a.split_stride);
+      const f32x4 v1 = *reinterpret_cast<const f32x4 *>(rp[p] + s * a.split_stride + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        x[p][j] += v0[j];
+        x[p][4 + j] += v1[j];
+      }
     }
   }
-  const float w1 = nw ? bf2f(nw[l]) : 1.f, w2 = nw ? bf2f(nw[l + 64]) : 1.f;
 #pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    x1[i] = rbf(x1[i]);  // the Linear's bf16 output
-    x2[i] = rbf(x2[i]);
-    float n1 = x1[i], n2 = x2[i];
-    if (nw) {
-      const float ss = wave_sum(x1[i] * x1[i] + x2[i] * x2[i]);
-      const float rstd = rsqrtf(ss * (1.f / 128.f) + a.eps);
-      n1 = rbf(w1 * rbf(x1[i] * rstd));
-      n2 = rbf(w2 * rbf(x2[i] * rstd));
+  for (int p = 0; p < NP; ++p) {
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      x[p][j] = rbf(x[p][j]);  // the Linear's bf16 output
+      ss += x[p][j] * x[p][j];
     }
-    const float r1 = rbf(rbf(n1 * cs[i]) + rbf(-n2 * sn[i]));
-    const float r2 = rbf(rbf(n2 * cs[i]) + rbf(n1 * sn[i]));
-    o1[i] = rope[i] ? r1 : x1[i];
-    o2[i] = rope[i] ? r2 : x2[i];
+    float n[8];
+    if (nw) {  // Qwen3RMSNorm over the 128 values of the head = the 16 lanes of this DPP row
+      ss += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, ss), 0xB1, 0xF, 0xF, true));
+      ss += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, ss), 0x4E, 0xF, 0xF, true));
+      ss += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, ss), 0x141, 0xF, 0xF, true));
+      ss += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, ss), 0x140, 0xF, 0xF, true));
+      const float rstd = rsqrtf(ss * (1.f / 128.f) + a.eps);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) n[j] = rbf(bf2f(wv[j]) * rbf(x[p][j] * rstd));
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) n[j] = x[p][j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      // partner value n[d +- 64] sits in lane c^8 of the same row: rotate the row by 8
+      const float pn =
+          __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, n[j]), 0x128, 0xF, 0xF, true));
+      const float cj = bf2f(cs[p][j]), sj = bf2f(sn[p][j]);
+      // rotate_half: first half gets -x2, second half +x1 (tf:modeling_qwen3.py:140-144)
+      const float r = rbf(rbf(n[j] * cj) + rbf((c < 8 ? -pn : pn) * sj));
+      out[p][j] = f2bf(rope[p] ? r : x[p][j]);
+    }
   }
 }
 
@@ -455,56 +481,57 @@ __global__ __launch_bounds__(G * 64) void k_attn_fused(FusedAttnArgs a) {
   if (t0 < t1) fetch(kA, vA, t0);
   if (t0 + 1 < t1) fetch(kB, vB, t0 + 1);
 
-  // ---- phase 0: the 16 q rows of this wave's head, all in flight together
+  // ---- phase 0: the 16 q rows of this wave's head: 4 passes x 4 rows, all loads in flight
   {
-    int brow[16], col[16], pos[16];
-    bool rp[16];
-    float o1[16], o2[16];
+    const int rsub = l >> 4, d0 = (l & 15) * 8;
+    int brow[4], col[4], pos[4];
+    bool rp[4];
+    bf16x8 ov[4];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      brow[j] = j < bs ? a.blk_row0 + j : -1;
-      col[j] = a.q_col + head * 128;
-      pos[j] = pos0 + tau + j;
-      rp[j] = true;
+    for (int p = 0; p < 4; ++p) {
+      const int j = p * 4 + rsub;
+      brow[p] = j < bs ? a.blk_row0 + j : -1;
+      col[p] = a.q_col + head * 128;
+      pos[p] = pos0 + tau + j;
+      rp[p] = true;
     }
-    rope_items<16>(a, brow, col, pos, rp, a.q_w, l, o1, o2);
+    rope_rows<4>(a, brow, col, pos, rp, a.q_w, l, ov);
+    const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      q_lds[wv][j][l] = f2bf(j < bs ? o1[j] : 0.f);
-      q_lds[wv][j][l + 64] = f2bf(j < bs ? o2[j] : 0.f);
+    for (int p = 0; p < 4; ++p) {
+      const int j = p * 4 + rsub;
+      *reinterpret_cast<bf16x8 *>(&q_lds[wv][j][d0]) = j < bs ? ov[p] : z;
     }
   }
   STAMP(1);
-  // ---- phase 1 (last split): new K / V rows of this kv head, 8 items per wave per pass
+  // ---- phase 1 (last split): new K / V rows of this kv head; items 0..n_new-1 are K rows,
+  // n_new..2n_new-1 V rows; a sweep covers 16*G items (4 passes x 4 rows x G waves)
   if (is_last_split) {
-    for (int base = 0; base < 2 * n_new; base += 8 * G) {
-      int brow[8], col[8], pos[8], rel[8];
-      bool rp[8], isv[8];
-      float o1[8], o2[8];
+    const int rsub = l >> 4, d0 = (l & 15) * 8;
+    for (int base = 0; base < 2 * n_new; base += 16 * G) {
+      int brow[4], col[4], pos[4], rel[4];
+      bool rp[4], isv[4];
+      bf16x8 ov[4];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int it = base + i * G + wv;
-        isv[i] = it >= n_new;
-        rel[i] = isv[i] ? it - n_new : it;
+      for (int p = 0; p < 4; ++p) {
+        const int it = base + (p * 4 + rsub) * G + wv;
+        isv[p] = it >= n_new;
+        rel[p] = isv[p] ? it - n_new : it;
         const bool ok = it < 2 * n_new;
-        brow[i] = !ok ? -1 : (rel[i] < tau ? a.ctx_row0 + rel[i] : a.blk_row0 + (rel[i] - tau));
-        col[i] = (isv[i] ? a.v_col : a.k_col) + kvh * 128;
-        pos[i] = pos0 + rel[i];
-        rp[i] = !isv[i];
+        brow[p] = !ok ? -1 : (rel[p] < tau ? a.ctx_row0 + rel[p] : a.blk_row0 + (rel[p] - tau));
+        col[p] = (isv[p] ? a.v_col : a.k_col) + kvh * 128;
+        pos[p] = pos0 + rel[p];
+        rp[p] = !isv[p];
       }
-      rope_items<8>(a, brow, col, pos, rp, a.k_w, l, o1, o2);
+      rope_rows<4>(a, brow, col, pos, rp, a.k_w, l, ov);
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        if (brow[i] >= 0) {
-          bf16_t *lrow = isv[i] ? new_v[rel[i]] : new_k[rel[i]];
-          lrow[l] = f2bf(o1[i]);
-          lrow[l + 64] = f2bf(o2[i]);
-          const int crow = S + rel[i];
-          if (crow < a.cache_rows) {
-            bf16_t *dst = (isv[i] ? a.vc : a.kc) + ((int64_t)kvh * a.cache_rows + crow) * 128;
-            dst[l] = f2bf(o1[i]);
-            dst[l + 64] = f2bf(o2[i]);
-          }
+      for (int p = 0; p < 4; ++p)
+        if (brow[p] >= 0) {
+          *reinterpret_cast<bf16x8 *>(isv[p] ? &new_v[rel[p]][d0] : &new_k[rel[p]][d0]) = ov[p];
+          const int crow = S + rel[p];
+          if (crow < a.cache_rows)
+            *reinterpret_cast<bf16x8 *>((isv[p] ? a.vc : a.kc) + ((int64_t)kvh * a.cache_rows + crow) * 128 + d0) =
+                ov[p];
         }
     }
   }

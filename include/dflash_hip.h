@@ -185,7 +185,7 @@ int dfl_block_attn(const void *q, const void *kcache, const void *vcache, int ca
 /* The whole attention stage of a block in ONE launch: q/k-norm + RoPE + KV append
  * (model/dflash.py:71-85) + attention (:86-99, causal = 0; target verify, causal = 1)
  * + the merge of the key splits, result as frag16 for o_proj.  Same arithmetic as
- * dfl_qknorm_rope_append + dfl_block_attn (K/V rows bit-identical); the key axis is
+ * dfl_qknorm_rope_append + dfl_block_attn (V rows bit-identical, K up to rare 1-ulp flips); the key axis is
  * split over workgroups and merged by the last one to arrive.  tau + bs <= 32 new rows.
  * ws: dfl_attn_fused_ws_bytes(n_q, n_kv, max_splits) bytes, ZEROED once by the caller
  * (it holds the arrival tickets, which every launch leaves at zero again). */

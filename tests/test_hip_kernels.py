@@ -377,8 +377,9 @@ def test_qknorm_rope_without_norm(ops):
                                                       (32, 8, 3000, 3, 16, True), (8, 2, 127, 1, 2, False)])
 def test_attn_fused_equals_three_launch_path(ops, n_q, n_kv, S, tau, bs, causal):
     """dfl_attn_fused (1 launch) vs dfl_qknorm_rope_append + dfl_block_attn (3 launches):
-    the appended K/V must be bit-identical, the attention output equal within the
-    rounding of a different key-split order, and both within tolerance of fp32 torch."""
+    the appended V must be bit-identical and K equal up to rare 1-ulp flips, the attention
+    output equal within the rounding of a different key-split order, and both within
+    tolerance of fp32 torch."""
     from dflash_amd.model import _rope_tables
     g = gen(S + n_q + bs)
     ld = (n_q + 2 * n_kv) * 128
@@ -410,7 +411,11 @@ def test_attn_fused_equals_three_launch_path(ops, n_q, n_kv, S, tau, bs, causal)
         out2.zero_()
         ops.attn_fused(**common, kcache=k2, vcache=v2, scale=128 ** -0.5, kv_len_max=S + tau + bs, ws=fws,
                        max_splits=32, out_frag=out2, causal=causal)
-    assert torch.equal(k1, k2) and torch.equal(v1, v2)
+    # V is a rounded copy: identical.  K differs only where the per-head RMS (summed in a
+    # different fp32 order by the two kernels) moves a value across a bf16 rounding edge.
+    assert torch.equal(v1, v2)
+    dk = (k1.float() - k2.float()).abs()
+    assert (dk > 0).float().mean() < 1e-3 and dk.max() <= 2 ** -7 * k1.float().abs().max()
     a = unfrag(out1, n_q * 128).float()[:bs]
     b = unfrag(out2, n_q * 128).float()[:bs]
     assert torch.isfinite(b).all()
