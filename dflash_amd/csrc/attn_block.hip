@@ -324,9 +324,8 @@ struct FusedAttnArgs {
 // brow < 0 marks an absent item (loads are clamped, outputs garbage, never stored).
 template <int NP>
 __device__ __forceinline__ void rope_rows(const FusedAttnArgs &a, const int (&brow)[NP], const int (&col)[NP],
-                                          const int (&pos)[NP], const bool (&rope)[NP], const bf16_t *nw_a,
-                                          const bf16_t *nw_b, int nfirst, int l, bf16x8 (&out)[NP]) {
-  // passes [0, nfirst) use norm weight nw_a (q rows), the rest nw_b (k rows); both null = no norm
+                                          const int (&pos)[NP], const bool (&rope)[NP], const bf16_t *nw, int l,
+                                          bf16x8 (&out)[NP]) {
   const int c = l & 15, d0 = c * 8;
   float x[NP][8];
   bf16x8 cs[NP], sn[NP];
@@ -341,12 +340,8 @@ __device__ __forceinline__ void rope_rows(const FusedAttnArgs &a, const int (&br
 #pragma unroll
     for (int j = 0; j < 8; ++j) x[p][j] = 0.f;
   }
-  const bool nw = nw_a != nullptr;
-  bf16x8 wa = {0, 0, 0, 0, 0, 0, 0, 0}, wb = wa;
-  if (nw) {
-    wa = *reinterpret_cast<const bf16x8 *>(nw_a + d0);
-    wb = *reinterpret_cast<const bf16x8 *>(nw_b + d0);
-  }
+  bf16x8 wv = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (nw) wv = *reinterpret_cast<const bf16x8 *>(nw + d0);
   for (int s = 0; s < a.nsplit_k; ++s) {
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
@@ -375,7 +370,7 @@ __device__ __forceinline__ void rope_rows(const FusedAttnArgs &a, const int (&br
       ss += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, ss), 0x140, 0xF, 0xF, true));
       const float rstd = rsqrtf(ss * (1.f / 128.f) + a.eps);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) n[j] = rbf(bf2f(p < nfirst ? wa[j] : wb[j]) * rbf(x[p][j] * rstd));
+      for (int j = 0; j < 8; ++j) n[j] = rbf(bf2f(wv[j]) * rbf(x[p][j] * rstd));
     } else {
 #pragma unroll
       for (int j = 0; j < 8; ++j) n[j] = x[p][j];
@@ -486,76 +481,60 @@ __global__ __launch_bounds__(G * 64) void k_attn_fused(FusedAttnArgs a) {
   if (t0 < t1) fetch(kA, vA, t0);
   if (t0 + 1 < t1) fetch(kB, vB, t0 + 1);
 
-  // ---- phases 0+1: the 16 q rows of this wave's head (4 passes x 4 rows) and, in the LAST
-  // split, the new K / V rows of this kv head (items 0..n_new-1 K rows, n_new..2n_new-1
-  // V rows; 4 more passes cover 16*G items).  One batched call so every load of both is in
-  // flight together (done one after the other they cost 4.4 + 5.8 us).
+  // ---- phase 0: the 16 q rows of this wave's head: 4 passes x 4 rows, all loads in flight
   {
     const int rsub = l >> 4, d0 = (l & 15) * 8;
-    const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-    auto q_item = [&](int p, int &brow, int &col, int &pos) {
+    int brow[4], col[4], pos[4];
+    bool rp[4];
+    bf16x8 ov[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
       const int j = p * 4 + rsub;
-      brow = j < bs ? a.blk_row0 + j : -1;
-      col = a.q_col + head * 128;
-      pos = pos0 + tau + j;
-    };
-    auto kv_item = [&](int base, int p, int &brow, int &col, int &pos, int &rel, bool &isv) {
-      const int it = base + (p * 4 + rsub) * G + wv;
-      isv = it >= n_new;
-      rel = isv ? it - n_new : it;
-      brow = it >= 2 * n_new ? -1 : (rel < tau ? a.ctx_row0 + rel : a.blk_row0 + (rel - tau));
-      col = (isv ? a.v_col : a.k_col) + kvh * 128;
-      pos = pos0 + rel;
-    };
-    auto kv_store = [&](int brow, int rel, bool isv, const bf16x8 &v) {
-      if (brow < 0) return;
-      *reinterpret_cast<bf16x8 *>(isv ? &new_v[rel][d0] : &new_k[rel][d0]) = v;
-      const int crow = S + rel;
-      if (crow < a.cache_rows)
-        *reinterpret_cast<bf16x8 *>((isv ? a.vc : a.kc) + ((int64_t)kvh * a.cache_rows + crow) * 128 + d0) = v;
-    };
-    if (!is_last_split) {
-      int brow[4], col[4], pos[4];
-      bool rp[4] = {true, true, true, true};
-      bf16x8 ov[4];
+      brow[p] = j < bs ? a.blk_row0 + j : -1;
+      col[p] = a.q_col + head * 128;
+      pos[p] = pos0 + tau + j;
+      rp[p] = true;
+    }
+    rope_rows<4>(a, brow, col, pos, rp, a.q_w, l, ov);
+    const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-      for (int p = 0; p < 4; ++p) q_item(p, brow[p], col[p], pos[p]);
-      rope_rows<4>(a, brow, col, pos, rp, a.q_w, a.q_w, 4, l, ov);
-#pragma unroll
-      for (int p = 0; p < 4; ++p) *reinterpret_cast<bf16x8 *>(&q_lds[wv][p * 4 + rsub][d0]) = brow[p] >= 0 ? ov[p] : z;
-    } else {
-      int brow[8], col[8], pos[8], rel[4];
-      bool rp[8], isv[4];
-      bf16x8 ov[8];
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        q_item(p, brow[p], col[p], pos[p]);
-        rp[p] = true;
-        kv_item(0, p, brow[4 + p], col[4 + p], pos[4 + p], rel[p], isv[p]);
-        rp[4 + p] = !isv[p];
-      }
-      rope_rows<8>(a, brow, col, pos, rp, a.q_w, a.k_w, 4, l, ov);
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        *reinterpret_cast<bf16x8 *>(&q_lds[wv][p * 4 + rsub][d0]) = brow[p] >= 0 ? ov[p] : z;
-        kv_store(brow[4 + p], rel[p], isv[p], ov[4 + p]);
-      }
-      for (int base = 16 * G; base < 2 * n_new; base += 16 * G) {  // only when 2*n_new > 16*G (G < 4)
-        int b2[4], c2[4], p2[4], r2[4];
-        bool rp2[4], v2[4];
-        bf16x8 o2[4];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          kv_item(base, p, b2[p], c2[p], p2[p], r2[p], v2[p]);
-          rp2[p] = !v2[p];
-        }
-        rope_rows<4>(a, b2, c2, p2, rp2, a.k_w, a.k_w, 4, l, o2);
-#pragma unroll
-        for (int p = 0; p < 4; ++p) kv_store(b2[p], r2[p], v2[p], o2[p]);
-      }
+    for (int p = 0; p < 4; ++p) {
+      const int j = p * 4 + rsub;
+      *reinterpret_cast<bf16x8 *>(&q_lds[wv][j][d0]) = j < bs ? ov[p] : z;
     }
   }
   STAMP(1);
+  // ---- phase 1 (last split): new K / V rows of this kv head; items 0..n_new-1 are K rows,
+  // n_new..2n_new-1 V rows; a sweep covers 16*G items (4 passes x 4 rows x G waves)
+  if (is_last_split) {
+    const int rsub = l >> 4, d0 = (l & 15) * 8;
+    for (int base = 0; base < 2 * n_new; base += 16 * G) {
+      int brow[4], col[4], pos[4], rel[4];
+      bool rp[4], isv[4];
+      bf16x8 ov[4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int it = base + (p * 4 + rsub) * G + wv;
+        isv[p] = it >= n_new;
+        rel[p] = isv[p] ? it - n_new : it;
+        const bool ok = it < 2 * n_new;
+        brow[p] = !ok ? -1 : (rel[p] < tau ? a.ctx_row0 + rel[p] : a.blk_row0 + (rel[p] - tau));
+        col[p] = (isv[p] ? a.v_col : a.k_col) + kvh * 128;
+        pos[p] = pos0 + rel[p];
+        rp[p] = !isv[p];
+      }
+      rope_rows<4>(a, brow, col, pos, rp, a.k_w, l, ov);
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+        if (brow[p] >= 0) {
+          *reinterpret_cast<bf16x8 *>(isv[p] ? &new_v[rel[p]][d0] : &new_k[rel[p]][d0]) = ov[p];
+          const int crow = S + rel[p];
+          if (crow < a.cache_rows)
+            *reinterpret_cast<bf16x8 *>((isv[p] ? a.vc : a.kc) + ((int64_t)kvh * a.cache_rows + crow) * 128 + d0) =
+                ov[p];
+        }
+    }
+  }
   __syncthreads();
   STAMP(2);
 
