@@ -85,48 +85,32 @@ __device__ __forceinline__ float row_sum16(float v) {
 // fragment loop so that the loads of one call are issued together; branching per fragment
 // serialised them with a vmcnt(0) each (8 L2 round trips, +6.5 us per launch, measured).
 template <int NF>
-__device__ __forceinline__ void load_x_raw(const RowSrc &s, const int (&ks)[NF], int l, int nv, bf16x8 (&x)[NF],
-                                           bf16x8 (&wv)[NF]) {
+__device__ __forceinline__ void build_x(const RowSrc &s, const int (&ks)[NF], const bool (&take)[NF], int l, int nv,
+                                        float rstd, bf16x8 (&x)[NF]) {
+  const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
   if (s.mode == 0) {
 #pragma unroll
     for (int f = 0; f < NF; ++f) x[f] = s.frag[(size_t)ks[f] * 64 + l];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) x[f] = take[f] ? x[f] : z;
     return;
   }
   const int m = l & 15, kq = l >> 4;
-  // nv < 0: the buffer is known to hold 16 rows (the residual stream), no clamp and no
-  // dependence on dyn; else never read past the caller's valid rows
-  const int mr = nv < 0 ? m : (m < nv ? m : (nv > 0 ? nv - 1 : 0));
+  const int mr = m < nv ? m : (nv > 0 ? nv - 1 : 0);  // never read past the caller's valid rows
   const bf16_t *row = s.rows + (int64_t)mr * s.ld + kq * 8;
 #pragma unroll
   for (int f = 0; f < NF; ++f) x[f] = *reinterpret_cast<const bf16x8 *>(row + ks[f] * 32);
-  if (s.mode == 2) {
+  if (s.mode == 2) {  // Qwen3RMSNorm: weight * bf16(x * rstd), tf:modeling_qwen3.py:59-64
+    bf16x8 wv[NF];
 #pragma unroll
     for (int f = 0; f < NF; ++f) wv[f] = *reinterpret_cast<const bf16x8 *>(s.nw + ks[f] * 32 + kq * 8);
-  }
-}
-
-template <int NF>
-__device__ __forceinline__ void finish_x(const RowSrc &s, const bool (&take)[NF], int l, int nv, float rstd,
-                                         bf16x8 (&x)[NF], const bf16x8 (&wv)[NF]) {
-  const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-  const int m = l & 15;
-  if (s.mode == 2) {  // Qwen3RMSNorm: weight * bf16(x * rstd), tf:modeling_qwen3.py:59-64
 #pragma unroll
     for (int f = 0; f < NF; ++f)
 #pragma unroll
       for (int j = 0; j < 8; ++j) x[f][j] = f2bf(bf2f(wv[f][j]) * rbf(bf2f(x[f][j]) * rstd));
   }
-  const bool rowok = s.mode == 0 || m < nv;
 #pragma unroll
-  for (int f = 0; f < NF; ++f) x[f] = (take[f] && rowok) ? x[f] : z;
-}
-
-template <int NF>
-__device__ __forceinline__ void build_x(const RowSrc &s, const int (&ks)[NF], const bool (&take)[NF], int l, int nv,
-                                        float rstd, bf16x8 (&x)[NF]) {
-  bf16x8 wv[NF];
-  load_x_raw<NF>(s, ks, l, nv, x, wv);
-  finish_x<NF>(s, take, l, nv, rstd, x, wv);
+  for (int f = 0; f < NF; ++f) x[f] = (take[f] && m < nv) ? x[f] : z;
 }
 
 template <int MT, bool CHUNKED, int EPI>
@@ -281,21 +265,6 @@ __global__ __launch_bounds__(1024) void k_gemm(GemmArgs a) {
   const int nitems = nseq * a.nch;
   if (nitems > 0) load_item(wA, xA, tile_of(0), 0);  // first weights leave for HBM before the prologue
 
-  // the wave's activation rows (raw) and norm weights go out now as well: they depend on
-  // neither rstd nor, for the 16-row residual buffer of a normed source, on dyn
-  int xks[FR];
-  bool xtake[FR];
-  bf16x8 xw[MT][FR];
-  if (!CHUNKED) {
-#pragma unroll
-    for (int f = 0; f < FR; ++f) {
-      xtake[f] = f < nf0;
-      xks[f] = xtake[f] ? ks0_of(0) + f : 0;
-    }
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) load_x_raw<FR>(a.src[mt], xks, l, a.src[mt].mode == 2 ? -1 : nv[mt], xr[mt], xw[mt]);
-  }
-
   // ---- (mode 2) the rows' rstd, computed while the first weights are in flight.  The nss partial sums of squares of a
   // row are summed by the 16 waves together: wave w takes partials w, w+16, ... with four
   // unconditional loads in flight per lane (a serial loop over all 256 cost ~20 us of
@@ -339,8 +308,15 @@ __global__ __launch_bounds__(1024) void k_gemm(GemmArgs a) {
   }
 
   if (!CHUNKED) {
+    int ks[FR];
+    bool take[FR];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) finish_x<FR>(a.src[mt], xtake, l, nv[mt], rstd[mt], xr[mt], xw[mt]);
+    for (int f = 0; f < FR; ++f) {
+      take[f] = f < nf0;
+      ks[f] = take[f] ? ks0_of(0) + f : 0;
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) build_x<FR>(a.src[mt], ks, take, l, nv[mt], rstd[mt], xr[mt]);
   }
 
   if (nitems > 0) {
