@@ -17,7 +17,7 @@ else
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf "$R/gpurun_out/pmc_$c"
     timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$R/gpurun_out/pmc_$c" -- \
-      python3 "$R/bench.py" --steps 6 --warmup 1 --no-cpu-baseline --target-layers 2 > "$R/gpurun_out/pmc_$c.json" 2> "$R/gpurun_out/pmc_$c.err"
+      python3 "$R/bench.py" --steps 6 --warmup 1 --no-cpu-baseline --target-layers 8 > "$R/gpurun_out/pmc_$c.json" 2> "$R/gpurun_out/pmc_$c.err"
     rc=$?
     echo "pmc $c rc=$rc"
     [ $rc -ne 0 ] && { tail -5 "$R/gpurun_out/pmc_$c.err"; exit $rc; }
