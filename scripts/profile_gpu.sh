@@ -13,7 +13,7 @@ if [ "$mode" = stats ]; then
   timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_stats" -- \
     python3 "$R/bench.py" --steps 24 --warmup 2 --no-cpu-baseline > "$R/gpurun_out/prof_stats.json" 2> "$R/gpurun_out/prof_stats.err"
   echo "stats rc=$?"
-else
+elif [ "$mode" = pmc ]; then
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf "$R/gpurun_out/pmc_$c"
     timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$R/gpurun_out/pmc_$c" -- \
@@ -24,3 +24,9 @@ else
   done
 fi
 ls -R "$R/gpurun_out" | head -40
+if [ "$mode" = mfma ]; then
+  rm -rf "$R/gpurun_out/pmc_mfma"
+  timeout -k 10 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$R/gpurun_out/pmc_mfma" -- \
+    python3 "$R/bench.py" --steps 6 --warmup 1 --no-cpu-baseline --target-layers 8 > "$R/gpurun_out/pmc_mfma.json" 2> "$R/gpurun_out/pmc_mfma.err"
+  echo "pmc mfma rc=$?"; tail -3 "$R/gpurun_out/pmc_mfma.err" | grep -v "^E2026\|^W2026"
+fi
