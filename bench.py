@@ -56,17 +56,27 @@ def make_hf_target(dev, layers=36):
     return m, impose_greedy_walk(m, seed=1234)   # large-margin greedy rule, see module docstring
 
 
-def tau_plan(n, bs, seed, mean_tau=7.3):
-    """k_c = number of agreeing draft tokens per cycle, tau = k+1 = 1 + min(Geom(p), bs-1)."""
+def tau_plan(n, bs, seed, mean_tau=7.3, block=20):
+    """k_c = number of agreeing draft tokens per cycle; tau = k + 1 = 1 + min(Geom(p), bs-1)
+    with p solving E[tau] = mean_tau.  Drawn in blocks of `block` cycles, each block
+    re-drawn (seeded) until its taus sum to round(block * mean_tau): any window the driver
+    times has the published mean acceptance length to within a fraction of a block."""
     lo, hi = 0.0, 1.0
     for _ in range(60):
         p = 0.5 * (lo + hi)
         m = 1.0 + sum(p ** j for j in range(1, bs))
         lo, hi = (p, hi) if m < mean_tau else (lo, p)
     g = torch.Generator().manual_seed(seed)
-    u = torch.rand(n, bs - 1, generator=g)
-    ok = (u < p).long().cumprod(dim=1).sum(dim=1)
-    return ok.tolist()
+    want = round(block * mean_tau)
+    out = []
+    while len(out) < n:
+        for _ in range(10000):
+            u = torch.rand(block, bs - 1, generator=g)
+            k = (u < p).long().cumprod(dim=1).sum(dim=1)
+            if int(k.sum()) + block == want:
+                break
+        out += k.tolist()
+    return out[:n]
 
 
 def gpu_leg(args, rank, world, dev):
@@ -120,7 +130,7 @@ def gpu_leg(args, rank, world, dev):
         s.cycle(bs)
 
     ev_all = []
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -131,7 +141,7 @@ def gpu_leg(args, rank, world, dev):
         ev_all.append(s.events)
         tokens += r.tau
     torch.cuda.synchronize()
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
     s.events = None
@@ -264,7 +274,8 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    if world > 1:
+    use_pg = "RANK" in os.environ   # launched by torch.distributed.run (also with one rank: same code path)
+    if use_pg:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.distributed.init_process_group("nccl", device_id=dev)  # RCCL; timing scalars only
 
@@ -284,7 +295,7 @@ def main():
             "config": {"workload": "Qwen3-8B-shaped target (" + ("HF/PyTorch-ROCm verify" if args.hf_verify else
                                    "HF prefill, NativeTarget verify on the kernels") + ") + DFlash-b16 5-layer draft, "
                                    f"block=16, temp=0, batch=1 per GPU, prefix={args.prefix}, random-init weights, "
-                                   "scripted acceptance (seeded truncated-geometric, mean tau 7.3)",
+                                   "scripted acceptance (seeded truncated-geometric, mean tau 7.3 per 20-cycle block)",
                        "target_layers": args.target_layers, "requests": world,
                        "target_verify": "hf" if args.hf_verify else "native", "parallelism": f"dp{world}"},
             "mean_acceptance_length": res["mean_tau"], "raw_tau1_value": res["raw_tau1_value"],
@@ -292,7 +303,7 @@ def main():
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_pg:
         torch.distributed.destroy_process_group()
 
 
