@@ -373,3 +373,68 @@ def test_native_target_llama_style():
     r = ref.hidden_states[2][0].float()
     assert (taps[:12, :512].float() - r).abs().max() <= 4e-2 * r.abs().max()
     assert torch.equal(post[0], torch.argmax(logits[:12], dim=-1))
+
+
+def test_full_size_draft_cycle_matches_oracle():
+    """BASELINE.json's full shapes (Qwen3-8B-DFlash-b16: H 4096, 5 layers, 32/8 heads,
+    FFN 12288, 5 taps): a prompt-context cycle and a steady cycle of the draft forward
+    against the CPU oracle with the same seeded weights; then the fused lm_head+argmax on
+    a 151936-row head against the oracle's logits (margin-screened ids)."""
+    from oracle import dflash_oracle as O
+    from dflash_amd.config import DFlashConfig, QWEN3_8B_DRAFT
+    torch.set_num_threads(max(8, torch.get_num_threads()))
+    cfg = DFlashConfig(**QWEN3_8B_DRAFT)
+    w = H.draft_weights(cfg, seed=11, dtype=BF16)
+    from dflash_amd import DFlashDraftModel
+    m = DFlashDraftModel(cfg, device=dev())
+    m.load_state_dict(w)
+    oc = H.oracle_cfg(cfg, "sdpa")
+    g = torch.Generator().manual_seed(5)
+    ocache = O.ListKVCache()
+    cache = m.new_cache(256)
+    start = 40
+    for c, (ctx, bs, tau_next) in enumerate(((40, 16, 7), (7, 16, 16))):
+        th = (torch.randn(1, ctx, cfg.fc_in, generator=g) * 1.5).to(BF16)
+        ne = (torch.randn(1, bs, cfg.hidden_size, generator=g) * 0.05).to(BF16)
+        pos = torch.arange(ocache.get_seq_length(), start + bs)[None]
+        ref = O.draft_forward(w, oc, position_ids=pos, noise_embedding=ne, target_hidden=th, cache=ocache)
+        ocache.crop(start)
+        got = m(target_hidden=th.to(dev()), noise_embedding=ne.to(dev()), position_ids=pos.to(dev()),
+                past_key_values=cache, use_cache=True, is_causal=False)
+        cache.crop(start)
+        d = (got.float().cpu() - ref.float()).abs()
+        scale = ref.float().abs().max()
+        assert d.max() <= 4e-2 * scale and d.mean() <= 4e-3 * scale, (c, float(d.max()), float(scale))
+        start += tau_next
+    # lm_head at full vocabulary on the last cycle's hidden rows
+    lm = (torch.randn(cfg.vocab_size, cfg.hidden_size, generator=g) * 0.02).to(BF16)
+    ref_logits = torch.nn.functional.linear(ref[0, 1:], lm).float()
+    wp = m.packed_lm_head(lm.to(dev()))
+    ids = torch.zeros(16, dtype=torch.long, device=dev())
+    m.draft_tokens(m._src["final"], wp, 16, ids)
+    top2 = ref_logits.topk(2, dim=-1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 8e-2 * ref_logits.abs().max()
+    assert torch.equal(ids[1:].cpu()[safe], ref_logits.argmax(-1)[safe])
+    assert (ids[1:].cpu() == ref_logits.argmax(-1)).float().mean() >= 0.6
+
+
+def test_long_prefix_many_key_splits():
+    """Prefix far beyond the bench's 1k (S = 9000: the key-split count saturates at
+    max_splits, every split walks many tiles): native verify vs the HF forward."""
+    from transformers import DynamicCache
+    from dflash_amd import NativeTarget
+    hf = _tiny_hf(layers=2)
+    nt = NativeTarget(hf, max_splits=8)
+    g = torch.Generator().manual_seed(12)
+    P = 9000
+    prompt = torch.randint(0, 2000, (1, P), generator=g).to(dev())
+    block = torch.randint(0, 2000, (1, 16), generator=g).to(dev())
+    cache = nt.new_cache(P + 64)
+    nt.prefill(prompt, cache)
+    logits = torch.zeros(16, 2048, dtype=BF16, device=dev())
+    nt.verify(block[0], P, cache, logits_out=logits)
+    rc = DynamicCache()
+    hf(prompt, past_key_values=rc, use_cache=True)
+    ref = hf(block, position_ids=torch.arange(P, P + 16, device=dev())[None], past_key_values=rc, use_cache=True)
+    rl = ref.logits[0].float()
+    assert (logits.float() - rl).abs().max() <= 4e-2 * rl.abs().max()
