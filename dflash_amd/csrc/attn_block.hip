@@ -18,6 +18,7 @@
 // MFMA is used here and only here for attention math; the work is ~0.3 GFLOP per
 // layer and 4 MB of K/V at S=1k, i.e. latency-bound, not a roofline kernel.
 #include "dfl_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -505,15 +506,17 @@ __global__ __launch_bounds__(G * 64) void k_attn_fused(FusedAttnArgs a) {
   }
   STAMP(1);
   // ---- phase 1 (last split): new K / V rows of this kv head; items 0..n_new-1 are K rows,
-  // n_new..2n_new-1 V rows; a sweep covers 16*G items (4 passes x 4 rows x G waves)
+  // n_new..2n_new-1 V rows; a sweep of NP passes covers 4*NP*G items.  Two passes suffice
+  // for the target verify (16 new rows), the draft (tau + 16 rows) takes four.
   if (is_last_split) {
     const int rsub = l >> 4, d0 = (l & 15) * 8;
-    for (int base = 0; base < 2 * n_new; base += 16 * G) {
-      int brow[4], col[4], pos[4], rel[4];
-      bool rp[4], isv[4];
-      bf16x8 ov[4];
+    auto sweep = [&](auto np_tag, int base) {
+      constexpr int NP = decltype(np_tag)::value;
+      int brow[NP], col[NP], pos[NP], rel[NP];
+      bool rp[NP], isv[NP];
+      bf16x8 ov[NP];
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
+      for (int p = 0; p < NP; ++p) {
         const int it = base + (p * 4 + rsub) * G + wv;
         isv[p] = it >= n_new;
         rel[p] = isv[p] ? it - n_new : it;
@@ -523,9 +526,9 @@ __global__ __launch_bounds__(G * 64) void k_attn_fused(FusedAttnArgs a) {
         pos[p] = pos0 + rel[p];
         rp[p] = !isv[p];
       }
-      rope_rows<4>(a, brow, col, pos, rp, a.k_w, l, ov);
+      rope_rows<NP>(a, brow, col, pos, rp, a.k_w, l, ov);
 #pragma unroll
-      for (int p = 0; p < 4; ++p)
+      for (int p = 0; p < NP; ++p)
         if (brow[p] >= 0) {
           *reinterpret_cast<bf16x8 *>(isv[p] ? &new_v[rel[p]][d0] : &new_k[rel[p]][d0]) = ov[p];
           const int crow = S + rel[p];
@@ -533,6 +536,11 @@ __global__ __launch_bounds__(G * 64) void k_attn_fused(FusedAttnArgs a) {
             *reinterpret_cast<bf16x8 *>((isv[p] ? a.vc : a.kc) + ((int64_t)kvh * a.cache_rows + crow) * 128 + d0) =
                 ov[p];
         }
+    };
+    if (2 * n_new <= 8 * G) {
+      sweep(std::integral_constant<int, 2>{}, 0);
+    } else {
+      for (int base = 0; base < 2 * n_new; base += 16 * G) sweep(std::integral_constant<int, 4>{}, base);
     }
   }
   __syncthreads();
