@@ -22,6 +22,14 @@ class Rows(C.Structure):
 
 _r = C.POINTER(Rows)
 
+
+class RowsBatch(C.Structure):
+    """dfl_rows_batch of include/dflash_hip.h."""
+    _fields_ = [("r0", Rows), ("frag_stride", C.c_int64), ("rows_stride", C.c_int64), ("ss_stride", C.c_int64)]
+
+
+_rb = C.POINTER(RowsBatch)
+
 # name -> (restype, argtypes); mirrors include/dflash_hip.h one to one
 SIGNATURES = {
     "dfl_version": (_i, []),
@@ -46,6 +54,21 @@ SIGNATURES = {
                             _i, _p, _i, _p, _p]),
     "dfl_argmax": (_i, [_p, _i, _i, _i64, _p, _p]),
     "dfl_accept_commit": (_i, [_p, _p, _i, _p, _i64, _p, _p, _i, _p, _p]),
+    # ---- ragged batch of requests
+    "dfl_batch_tiles": (_i, [_i]),
+    "dfl_batch_ksplit": (_i, [_i]),
+    "dfl_gemm_batch_ws_bytes": (_i64, [_i, _i]),
+    "dfl_gemm_f32_batch": (_i, [_p, _rb, _i, _i, _i, _p, _p, _p]),
+    "dfl_gemm_silu_mul_batch": (_i, [_p, _rb, _i, _i, _i, _p, _i64, _p, _p, _p]),
+    "dfl_gemm_resid_batch": (_i, [_p, _rb, _i, _i, _i, _p, _i64, _i64, _i, _p, _i64, _i64, _p, _i64, _p, _p, _p]),
+    "dfl_gemm_argmax_batch": (_i, [_p, _rb, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i64, _i, _p, _i64, _p]),
+    "dfl_embed_rows_batch": (_i, [_p, _p, _i64, _i, _p, _i64, _i, _p, _i64, _p, _i, _p]),
+    "dfl_kv_append_batch": (_i, [_p, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i64, _f, _p, _p, _i, _p, _p, _i,
+                                 _i64, _i64, _p, _p]),
+    "dfl_attn_fused_batch_ws_bytes": (_i64, [_i, _i, _i, _i]),
+    "dfl_attn_fused_batch": (_i, [_p, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _f, _p, _p, _i, _p, _p, _i,
+                                  _i64, _f, _i, _p, _i, _p, _i, _p, _i64, _p]),
+    "dfl_accept_commit_batch": (_i, [_p, _i64, _p, _i64, _i, _p, _i64, _i64, _p, _p, _p, _i, _p, _p, _i64, _p]),
 }
 
 _lib = None

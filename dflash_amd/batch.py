@@ -1,0 +1,334 @@
+"""Ragged batch of requests on one GPU: R <= 4 requests advance one decode cycle together
+and share every weight byte of the draft forward, the lm_head and the target verify
+(BASELINE.json configs[2]: 32 requests over 8 GPUs = 4 per GPU).
+
+The reference has no batched form of the path: `spec_generate` is batch-1 by construction
+(model/dflash.py:206-211,258) and its "batched" harness is a Python loop over prompts
+(benchmark_batched.py:212-243, benchmark.py:445-470).  `dflash_generate_batch` therefore
+keeps that contract — a list of prompts in, one `dflash_generate` namespace per prompt out,
+each identical to what the single-request loop returns for that prompt — and changes only
+how the cycles are executed: per cycle ONE pass over the weights for all live requests
+(dfl_*_batch kernels), per-request lengths S / tau / start held on the device (`dyn`),
+per-request preallocated KV caches, one device->host read of R x 4 ints.
+
+Needs the native target (`dflash_amd.NativeTarget`): the HF forward cannot take requests
+of different lengths without padding masks, which is exactly the cost this path removes.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Callable, Optional, Sequence
+
+import torch
+
+from . import ops
+from .generate import _bf16_table, _taps, _trim, cuda_time
+from .model import DFlashDraftModel, DFlashKVCache
+from .target import NativeTarget, TargetKVCache
+from .utils import sample
+
+BF16, F32, I32, I64 = torch.bfloat16, torch.float32, torch.int32, torch.int64
+MAX_GROUP = 4
+
+
+class _View:
+    """One request's slice of the group caches, with the fields the single-request
+    prefill code expects (DFlashKVCache / TargetKVCache)."""
+
+    def __init__(self, k, v, dyn, max_rows):
+        self.k, self.v, self.dyn, self.max_rows, self.length = k, v, dyn, max_rows, 0
+
+    def get_seq_length(self, layer_idx: int = 0) -> int:
+        return self.length
+
+
+class BatchedDecoder:
+    """Device state and per-cycle launch sequence of one group of R <= 4 requests."""
+
+    def __init__(self, model: DFlashDraftModel, target: NativeTarget, n_requests: int, max_rows: int,
+                 out_len: int, mask_token_id: int, stop_token_ids=None, max_splits: int = 32):
+        if not isinstance(target, NativeTarget):
+            raise TypeError("BatchedDecoder needs a dflash_amd.NativeTarget (see module docstring)")
+        if not 1 <= n_requests <= MAX_GROUP:
+            raise ValueError(f"a group holds 1..{MAX_GROUP} requests")
+        if model.w is None:
+            raise RuntimeError("draft weights not loaded")
+        c, t = model.config, target
+        if c.hidden_size != t.H:
+            raise ValueError("draft and target hidden sizes differ")
+        self.model, self.target, self.cfg = model, target, c
+        self.R, self.MT = n_requests, ops.batch_tiles(n_requests)
+        self.dev = dev = model.device
+        self.max_rows, self.out_len, self.mask_id = int(max_rows), int(out_len), int(mask_token_id)
+        self.max_splits = max_splits
+        R, MT, H, I = self.R, self.MT, c.hidden_size, c.intermediate_size
+        z = lambda *s, dt=BF16: torch.zeros(*s, dtype=dt, device=dev)  # noqa: E731
+
+        # ---- lengths (device): draft form and block form, see dfl_accept_commit_batch
+        self.dyn_d, self.dyn_t = z(MT, 8, dt=I32), z(MT, 8, dt=I32)
+        # ---- caches [request][layer][kv head][row][128]
+        Ld, Lt = c.num_hidden_layers, t.L
+        self.dk, self.dv = z(MT, Ld, c.num_key_value_heads, max_rows, 128), z(MT, Ld, c.num_key_value_heads, max_rows, 128)
+        self.tk, self.tv = z(MT, Lt, t.n_kv, max_rows, 128), z(MT, Lt, t.n_kv, max_rows, 128)
+        # ---- ids
+        self.block = torch.full((MT, 16), self.mask_id, dtype=I64, device=dev)
+        self.post = z(MT, 16, dt=I64)
+        self.result = z(MT, 4, dt=I32)
+        self.output_ids = torch.full((MT, out_len), self.mask_id, dtype=I64, device=dev)
+        self.stop_t = torch.tensor(stop_token_ids, dtype=I64, device=dev) if stop_token_ids else None
+        # ---- draft scratch
+        self.nqkv_d = c.q_dim + 2 * c.kv_dim
+        self.nkv_all = Ld * 2 * c.kv_dim
+        ks = ops.batch_ksplit
+        self.d = dict(h=z(MT, 16, H), ctxh=z(MT, 16, H), ss_emb=z(MT, 16, dt=F32), ss_h=z(MT, H, dt=F32),
+                      ss_ctx=z(MT, H, dt=F32), attn=z(MT, 16 * c.q_dim), act=z(MT, 16 * I),
+                      part_qkv=z(ks(H) * MT * 16 * self.nqkv_d, dt=F32), part_kv=z(ks(H) * MT * 16 * self.nkv_all, dt=F32),
+                      taps=z(MT, 16, c.fc_in))
+        # context K/V weights of all layers as ONE packed weight: the k/v column tiles of each
+        # layer's packed qkv, concatenated (tile-major layout: a plain cat of tile ranges)
+        L = model.w["layers"]
+        self.kv_all = torch.cat([lw["qkv"][c.q_dim * H:] for lw in L]).contiguous()
+        self.k_norm_all = torch.stack([lw["k_norm"] for lw in L]).contiguous()
+        # ---- target scratch
+        self.nqkv_t = t.nqkv
+        self.t = dict(h=z(MT, 16, H), ss_emb=z(MT, 16, dt=F32), ss_h=z(MT, H, dt=F32), attn=z(MT, 16 * t.q_dim),
+                      act=z(MT, 16 * t.I), part_qkv=z(ks(H) * MT * 16 * t.nqkv, dt=F32))
+        # ---- shared workspaces (launches are stream-ordered)
+        nmax = max(c.vocab_size, t.V, 2 * I, 2 * t.I)
+        kmax = max(H, I, t.I, c.fc_in, c.q_dim)
+        self.gws = torch.zeros(max(ops.lib().dfl_gemm_batch_ws_bytes(n, k) for n, k in
+                                   ((nmax, H), (H, kmax))), dtype=torch.uint8, device=dev)
+        # one per model: the arrival tickets sit behind the partials, whose size depends on n_q
+        self.aws_d = ops.attn_fused_batch_ws(MT, c.num_attention_heads, c.num_key_value_heads, max_splits, dev)
+        self.aws_t = ops.attn_fused_batch_ws(MT, t.n_q, t.n_kv, max_splits, dev)
+        # ---- row sources
+        eps, nt = c.rms_norm_eps, H // 16
+        d, tt = self.d, self.t
+        self.src_d = dict(
+            taps=ops.brows_plain(d["taps"], ops.DYN_TAU),
+            ctx=ops.brows_normed(d["ctxh"], d["ss_ctx"], nt, model.w["hidden_norm"], eps, ops.DYN_TAU),
+            ln1=[ops.brows_normed(d["h"], d["ss_emb"] if i == 0 else d["ss_h"], 1 if i == 0 else nt, lw["ln1"], eps,
+                                  ops.DYN_BS) for i, lw in enumerate(L)],
+            ln2=[ops.brows_normed(d["h"], d["ss_h"], nt, lw["ln2"], eps, ops.DYN_BS) for lw in L],
+            final=ops.brows_normed(d["h"], d["ss_h"], nt, model.w["norm"], eps, ops.DYN_BS),
+            attn=ops.brows_frag(d["attn"]), act=ops.brows_frag(d["act"]))
+        self.src_t = dict(
+            ln1=[ops.brows_normed(tt["h"], tt["ss_emb"] if i == 0 else tt["ss_h"], 1 if i == 0 else nt, lw["ln1"],
+                                  t.eps, ops.DYN_BS) for i, lw in enumerate(t.layers)],
+            ln2=[ops.brows_normed(tt["h"], tt["ss_h"], nt, lw["ln2"], t.eps, ops.DYN_BS) for lw in t.layers],
+            final=ops.brows_normed(tt["h"], tt["ss_h"], nt, t.norm, t.eps, ops.DYN_BS),
+            attn=ops.brows_frag(tt["attn"]), act=ops.brows_frag(tt["act"]))
+        self.lm_wp = None
+        self.embed_w = None
+        # ---- host mirror of the lengths
+        self.start = [0] * R
+        self.n_in = [0] * R
+        self.live = [False] * R
+        self.hook_calls = [0] * R
+        self.bs = [16] * R
+
+    # ------------------------------------------------------------------ admission
+    @torch.inference_mode()
+    def admit(self, r: int, input_ids: torch.Tensor, temperature: float = 0.0) -> None:
+        """Prefill request r (model/dflash.py:218-229): target prefill through the wrapped
+        model, K/V into the group cache, first token sampled, the prompt's context rows
+        projected into the draft cache except the last <= 16, which become the first
+        cycle's context tile."""
+        m, t, c = self.model, self.target, self.cfg
+        if input_ids.shape[0] != 1 or not input_ids.is_cuda:
+            raise ValueError("admit: input_ids must be a [1, P] GPU tensor")
+        P = input_ids.shape[1]
+        if P + 2 * 16 > self.max_rows or P + 1 > self.out_len:
+            raise ValueError("admit: prompt does not fit the group's caches")
+        if self.lm_wp is None:
+            self.lm_wp = m.packed_lm_head(t.lm_head)
+            t.share_lm_head(self.lm_wp)
+            self.embed_w = _bf16_table(t.model.embed_tokens.weight, self.dev)
+        tc = _View(self.tk[r], self.tv[r], None, self.max_rows)
+        out = t.prefill(input_ids, tc, output_hidden_states=True)
+        self.output_ids[r].fill_(self.mask_id)
+        self.output_ids[r, :P] = input_ids[0]
+        first = sample(out.logits, temperature)
+        self.output_ids[r, P:P + 1] = first[0]
+        th = _taps(out.hidden_states, m.target_layer_ids)[0]          # [P, fc_in]
+        n_tail = min(16, P)
+        dc = _View(self.dk[r], self.dv[r], torch.zeros(8, dtype=I32, device=self.dev), self.max_rows)
+        if P > n_tail:
+            m.prefill_context(dc, th[:P - n_tail], 0)
+        self.d["taps"][r].zero_()
+        self.d["taps"][r, :n_tail] = th[P - n_tail:]
+        self.block[r].fill_(self.mask_id)
+        self.block[r, 0:1] = first[0]
+        S = P - n_tail
+        self.dyn_d[r] = torch.tensor([S, n_tail, 16, S, P, 0, 0, 0], dtype=I32)
+        self.dyn_t[r] = torch.tensor([P, 0, 16, P, P, 0, 0, 0], dtype=I32)
+        self.start[r], self.n_in[r], self.live[r], self.hook_calls[r], self.bs[r] = P, P, True, 0, 16
+
+    def park(self, r: int) -> None:
+        """Request r is finished: its tile stays in the launches but does no work."""
+        self.live[r] = False
+        self.dyn_d[r, ops.DYN_TAU:ops.DYN_BS + 1] = 0
+        self.dyn_t[r, ops.DYN_BS] = 0
+
+    def set_block_size(self, r: int, bs: int) -> None:
+        """Tail clamp (benchmark.py:104-105): a host write only when the size changes."""
+        if bs != self.bs[r]:
+            self.dyn_d[r, ops.DYN_BS] = bs
+            self.dyn_t[r, ops.DYN_BS] = bs
+            self.bs[r] = bs
+
+    # ------------------------------------------------------------------ one cycle
+    def _kv_len_max(self) -> int:
+        return max([self.start[r] for r in range(self.R) if self.live[r]] + [1]) + 16
+
+    def draft(self) -> None:
+        """Draft forward + lm_head + greedy unmask for every live request
+        (model/dflash.py:237-247): block[r, 1:bs] <- argmax."""
+        m, c, d, s, R, MT = self.model, self.cfg, self.d, self.src_d, self.R, self.MT
+        H, I = c.hidden_size, c.intermediate_size
+        L = m.w["layers"]
+        kvmax = self._kv_len_max()
+        cos, sin = m._rope_tab(kvmax + 64)
+        ops.embed_rows_batch(self.embed_w, self.block, R, d["h"], H, d["ss_emb"], self.dyn_t, ops.DYN_BS)
+        # context rows: fc, then K/V of all layers appended to the draft caches
+        ops.gemm_resid_batch(m.w["fc"], s["taps"], R, H, c.fc_in, d["ctxh"], add_residual=False, ws=self.gws,
+                             dyn=self.dyn_d, ss_out=d["ss_ctx"])
+        ops.gemm_f32_batch(self.kv_all, s["ctx"], R, self.nkv_all, H, d["part_kv"], self.dyn_d)
+        nsp = ops.batch_ksplit(H)
+        ops.kv_append_batch(kv=d["part_kv"], nsplit=nsp, split_stride=MT * 16 * self.nkv_all, ld=self.nkv_all, k_col=0,
+                            v_col=c.kv_dim, col_layer_stride=2 * c.kv_dim, n_layers=c.num_hidden_layers, R=R,
+                            n_kv=c.num_key_value_heads, k_norm_w=self.k_norm_all, eps=c.rms_norm_eps, cos_tab=cos,
+                            sin_tab=sin, kcache=self.dk, vcache=self.dv, dyn=self.dyn_d)
+        # block rows
+        for i, lw in enumerate(L):
+            ops.gemm_f32_batch(lw["qkv"], s["ln1"][i], R, self.nqkv_d, H, d["part_qkv"], self.dyn_t)
+            ops.attn_fused_batch(qkv=d["part_qkv"], nsplit=nsp, split_stride=MT * 16 * self.nqkv_d, ld=self.nqkv_d,
+                                 q_col=0, k_col=c.q_dim, v_col=c.q_dim + c.kv_dim, R=R, n_q=c.num_attention_heads,
+                                 n_kv=c.num_key_value_heads, q_norm_w=lw["q_norm"], k_norm_w=lw["k_norm"],
+                                 eps=c.rms_norm_eps, cos_tab=cos, sin_tab=sin, kcache=self.dk, vcache=self.dv, layer=i,
+                                 scale=c.head_dim ** -0.5, causal=False, dyn=self.dyn_t, kv_len_max=kvmax,
+                                 ws=self.aws_d, max_splits=self.max_splits, out_frag=d["attn"])
+            ops.gemm_resid_batch(lw["o"], s["attn"], R, H, c.q_dim, d["h"], add_residual=True, ws=self.gws,
+                                 dyn=self.dyn_t, ss_out=d["ss_h"])
+            ops.gemm_silu_mul_batch(lw["gu"], s["ln2"][i], R, I, H, d["act"], self.gws, self.dyn_t)
+            ops.gemm_resid_batch(lw["down"], s["act"], R, H, I, d["h"], add_residual=True, ws=self.gws,
+                                 dyn=self.dyn_t, ss_out=d["ss_h"])
+        ops.gemm_argmax_batch(self.lm_wp, s["final"], R, c.vocab_size, H, 1, 15, self.gws, self.block, 1,
+                              self.dyn_t, nrows_dyn_word=ops.DYN_BS)
+
+    def verify(self) -> None:
+        """Target verify of every live request's block (model/dflash.py:249-257, T = 0):
+        post[r] <- the target's greedy tokens, taps[r] <- the tapped layers' hidden rows."""
+        t, tt, s, R, MT, H = self.target, self.t, self.src_t, self.R, self.MT, self.cfg.hidden_size
+        kvmax = self._kv_len_max()
+        cos, sin = t._rope_tab(kvmax + 64)
+        taps = self.d["taps"]
+        tl = list(self.model.target_layer_ids)
+        if max(tl) >= t.L - 1:
+            raise NotImplementedError("tapping the last layer (post-norm state) is not supported")
+        nsp = ops.batch_ksplit(H)
+        ops.embed_rows_batch(t.embed, self.block, R, tt["h"], H, tt["ss_emb"], self.dyn_t, ops.DYN_BS)
+        for i, lw in enumerate(t.layers):
+            ops.gemm_f32_batch(lw["qkv"], s["ln1"][i], R, t.nqkv, H, tt["part_qkv"], self.dyn_t)
+            ops.attn_fused_batch(qkv=tt["part_qkv"], nsplit=nsp, split_stride=MT * 16 * t.nqkv, ld=t.nqkv, q_col=0,
+                                 k_col=t.q_dim, v_col=t.q_dim + t.kv_dim, R=R, n_q=t.n_q, n_kv=t.n_kv,
+                                 q_norm_w=lw["q_norm"], k_norm_w=lw["k_norm"], eps=t.eps, cos_tab=cos, sin_tab=sin,
+                                 kcache=self.tk, vcache=self.tv, layer=i, scale=128 ** -0.5, causal=True,
+                                 dyn=self.dyn_t, kv_len_max=kvmax, ws=self.aws_t, max_splits=self.max_splits,
+                                 out_frag=tt["attn"])
+            ops.gemm_resid_batch(lw["o"], s["attn"], R, H, t.q_dim, tt["h"], add_residual=True, ws=self.gws,
+                                 dyn=self.dyn_t, ss_out=tt["ss_h"])
+            ops.gemm_silu_mul_batch(lw["gu"], s["ln2"][i], R, t.I, H, tt["act"], self.gws, self.dyn_t)
+            tap = taps[:, :, tl.index(i) * H:(tl.index(i) + 1) * H] if i in tl else None
+            ops.gemm_resid_batch(lw["down"], s["act"], R, H, t.I, tt["h"], add_residual=True, ws=self.gws,
+                                 dyn=self.dyn_t, ss_out=tt["ss_h"], tap=tap)
+        ops.gemm_argmax_batch(self.lm_wp, s["final"], R, t.V, H, 0, 16, self.gws, self.post, 0, self.dyn_t,
+                              nrows_dyn_word=ops.DYN_BS)
+
+    def accept(self) -> list:
+        """Acceptance scan + commit + rollback bookkeeping of all requests (:258-268) and
+        the cycle's one device->host read.  Returns per request (tau, stop) or None."""
+        ops.accept_commit_batch(self.block, self.post, self.R, self.output_ids, self.dyn_d, self.dyn_t, self.stop_t,
+                                self.result, rearm_mask_id=self.mask_id)
+        res = self.result[:self.R].tolist()
+        out = []
+        for r in range(self.R):
+            if not self.live[r]:
+                out.append(None)
+                continue
+            self.start[r] = res[r][1]
+            out.append((res[r][0] + 1, bool(res[r][2])))
+        return out
+
+    @torch.inference_mode()
+    def cycle(self, draft_token_hook: Optional[Callable] = None) -> list:
+        """One decode cycle of every live request.  draft_token_hook(r, block_row, start,
+        call): test/bench instrumentation for scripted acceptance, as in DecodeSession."""
+        self.draft()
+        if draft_token_hook is not None:
+            for r in range(self.R):
+                if self.live[r]:
+                    draft_token_hook(r, self.block[r:r + 1], self.start[r], self.hook_calls[r])
+                    self.hook_calls[r] += 1
+        self.verify()
+        return self.accept()
+
+
+@torch.inference_mode()
+def dflash_generate_batch(model: DFlashDraftModel, target: NativeTarget, input_ids: Sequence[torch.Tensor],
+                          mask_token_id: int, max_new_tokens: int, block_size: int, stop_token_ids,
+                          temperature: float = 0.0, draft_token_hook: Optional[Callable] = None,
+                          group_size: int = MAX_GROUP) -> list:
+    """`dflash_generate` (benchmark.py:44-251) for a list of prompts: requests run in
+    groups of `group_size` <= 4 that share the weight stream; returns one namespace per
+    prompt with the fields of benchmark.py:242-251 (timing fields are the group's).
+    draft_token_hook(request_index, block, start, call)."""
+    if temperature >= 1e-5:
+        raise NotImplementedError("the batched loop is greedy (T = 0); use dflash_generate for T > 0")
+    if block_size != 16:
+        raise NotImplementedError("the batched kernels take 16-row blocks")
+    n = len(input_ids)
+    results = [None] * n
+    for g0 in range(0, n, group_size):
+        idx = list(range(g0, min(n, g0 + group_size)))
+        prompts = [input_ids[i] for i in idx]
+        pmax = max(p.shape[1] for p in prompts)
+        max_len = [p.shape[1] + max_new_tokens for p in prompts]
+        dec = BatchedDecoder(model, target, len(idx), max_rows=pmax + max_new_tokens + 3 * 16,
+                             out_len=pmax + max_new_tokens + 16, mask_token_id=mask_token_id,
+                             stop_token_ids=stop_token_ids)
+        t0 = cuda_time()
+        for r, p in enumerate(prompts):
+            dec.admit(r, p, temperature)
+        ttft = cuda_time() - t0
+        taus = [[] for _ in idx]
+        hook = (lambda r, blk, start, call: draft_token_hook(idx[r], blk, start, call)) if draft_token_hook else None
+        t1 = cuda_time()
+        first = True
+        stop_always = stop_token_ids is not None and mask_token_id in stop_token_ids
+        for r in range(len(idx)):   # nothing to generate
+            if dec.start[r] >= max_len[r]:
+                dec.park(r)
+        while any(dec.live):
+            for r in range(len(idx)):  # tail clamp (benchmark.py:104-105)
+                if dec.live[r]:
+                    dec.set_block_size(r, max(1, min(block_size, max_len[r] - dec.start[r])))
+            out = dec.cycle(hook)
+            if first:
+                first = False
+                t1 = cuda_time()   # TPOT excludes cycle 0 (benchmark.py:145-147)
+            for r, o in enumerate(out):
+                if o is None:
+                    continue
+                taus[r].append(o[0])
+                if o[1] or stop_always or dec.start[r] >= max_len[r]:
+                    dec.park(r)
+        decode_s = cuda_time() - t1
+        for r, i in enumerate(idx):
+            ids = _trim(dec.output_ids[r:r + 1], max_len[r], mask_token_id, stop_token_ids, dec.n_in[r])
+            n_out = ids.shape[1] - dec.n_in[r]
+            results[i] = SimpleNamespace(output_ids=ids.clone(), num_input_tokens=dec.n_in[r], num_output_tokens=n_out,
+                                         time_to_first_token=ttft, time_per_output_token=decode_s / max(1, n_out),
+                                         acceptance_lengths=taus[r], cycle_trace=[], profile_summary=None)
+        del dec
+    return results

@@ -99,6 +99,70 @@ __global__ __launch_bounds__(64) void k_accept_commit(const int64_t *block_ids, 
   }
 }
 
+// Ragged batch: one wavefront per request (grid.x = request).  Besides the draft-form
+// lengths dyn_d (S = rows kept in the draft cache, tau = context rows of the next cycle) it
+// maintains the block-form lengths dyn_t = {S = new start, tau = 0, pos0 = new start} which
+// the target verify AND the draft's block stage read, so that a steady-state cycle needs no
+// host-side length update at all.
+__global__ __launch_bounds__(64) void k_accept_commit_b(const int64_t *block_ids, int64_t blk_stride,
+                                                        const int64_t *posterior, int64_t post_stride,
+                                                        int64_t *output_ids, int64_t out_stride, int64_t output_len,
+                                                        int32_t *dyn_d, int32_t *dyn_t, const int64_t *stop_ids,
+                                                        int n_stop, int32_t *result, int64_t *next_block,
+                                                        int64_t mask_id) {
+  const int r = blockIdx.x, i = threadIdx.x;
+  if (next_block) next_block += r * blk_stride;
+  block_ids += r * blk_stride;
+  posterior += r * post_stride;
+  output_ids += r * out_stride;
+  dyn_d += r * DFL_DYN_WORDS;
+  dyn_t += r * DFL_DYN_WORDS;
+  const int start = dyn_d[DFL_DYN_START];
+  const int bs = dyn_d[DFL_DYN_BS];
+  const bool cmp = i < bs - 1;
+  const bool eq = cmp && (block_ids[i + 1] == posterior[i]);
+  const unsigned long long mism = __ballot(cmp && !eq);
+  const int acc = mism ? (int)__builtin_ctzll(mism) : bs - 1;
+  int64_t tok = -1;
+  if (i <= acc)
+    tok = block_ids[i];
+  else if (i == acc + 1)
+    tok = posterior[acc];
+  if (bs > 0 && i <= acc + 1 && start + i < output_len) output_ids[start + i] = tok;
+  bool hit = false;
+  if (bs > 0 && i <= acc + 1)
+    for (int s = 0; s < n_stop; ++s) hit |= (tok == stop_ids[s]);
+  const bool any_stop = __ballot(hit) != 0ull;
+  // the next cycle's block = output_ids[new start .. +bs) = [bonus token, mask, mask, ...]
+  // (model/dflash.py:235); all reads of block_ids above precede these writes in the wave
+  const int64_t bonus = __shfl(tok, acc + 1, 64);  // posterior[acc]; every lane takes part
+  if (next_block && bs > 0 && i < 16) next_block[i] = i == 0 ? bonus : mask_id;
+  if (i == 0 && bs > 0) {
+    const int new_start = start + acc + 1;
+    const int stop = dyn_d[DFL_DYN_STOP] | (any_stop ? 1 : 0);
+    const int cyc = dyn_d[DFL_DYN_CYCLE] + 1;
+    dyn_d[DFL_DYN_S] = start;
+    dyn_d[DFL_DYN_TAU] = acc + 1;
+    dyn_d[DFL_DYN_POS0] = start;
+    dyn_d[DFL_DYN_START] = new_start;
+    dyn_d[DFL_DYN_STOP] = stop;
+    dyn_d[DFL_DYN_CYCLE] = cyc;
+    dyn_t[DFL_DYN_S] = new_start;
+    dyn_t[DFL_DYN_TAU] = 0;
+    dyn_t[DFL_DYN_BS] = bs;
+    dyn_t[DFL_DYN_POS0] = new_start;
+    dyn_t[DFL_DYN_START] = new_start;
+    dyn_t[DFL_DYN_STOP] = stop;
+    dyn_t[DFL_DYN_CYCLE] = cyc;
+    if (result) {
+      result[r * 4 + 0] = acc;
+      result[r * 4 + 1] = new_start;
+      result[r * 4 + 2] = stop;
+      result[r * 4 + 3] = cyc;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int dfl_argmax(const void *logits, int dtype, int rows, int64_t V, int64_t *ids, void *stream) {
@@ -123,5 +187,20 @@ extern "C" int dfl_accept_commit(const int64_t *block_ids, const int64_t *poster
   hipLaunchKernelGGL(k_accept_commit, dim3(1), dim3(64), 0, (hipStream_t)stream, block_ids, posterior, bs, output_ids,
                      output_len, dyn, stop_ids, n_stop, result);
   DFL_CHECK_LAUNCH("dfl_accept_commit");
+  return DFL_OK;
+}
+
+extern "C" int dfl_accept_commit_batch(const int64_t *block_ids, int64_t blk_stride, const int64_t *posterior,
+                                       int64_t post_stride, int R, int64_t *output_ids, int64_t out_stride,
+                                       int64_t output_len, int32_t *dyn_d, int32_t *dyn_t, const int64_t *stop_ids,
+                                       int n_stop, int32_t *result, int64_t *next_block, int64_t mask_id,
+                                       void *stream) {
+  DFL_REQUIRE(block_ids && posterior && output_ids && dyn_d && dyn_t, "dfl_accept_commit_batch: null pointer");
+  DFL_REQUIRE(R >= 1 && R <= 1024, "dfl_accept_commit_batch: R=%d outside 1..1024", R);
+  DFL_REQUIRE(n_stop == 0 || stop_ids, "dfl_accept_commit_batch: n_stop>0 without stop_ids");
+  hipLaunchKernelGGL(k_accept_commit_b, dim3(R), dim3(64), 0, (hipStream_t)stream, block_ids, blk_stride, posterior,
+                     post_stride, output_ids, out_stride, output_len, dyn_d, dyn_t, stop_ids, n_stop, result, next_block,
+                     mask_id);
+  DFL_CHECK_LAUNCH("dfl_accept_commit_batch");
   return DFL_OK;
 }

@@ -314,6 +314,10 @@ struct FusedAttnArgs {
   float *o_part;   // [nsplit][n_q][16][128]
   float *ml_part;  // [nsplit][n_q][16][2]
   int *tickets;    // [n_kv], zero before the first launch; the merger leaves it zero
+  // ragged batch (grid.z = request): request r's rows sit req_rows further down the partial
+  // buffer, its cache / output / workspace at the strides below, its lengths at dyn + 8 r
+  int req_rows;
+  int64_t cache_req_stride, out_req_stride, opart_req_stride, ml_req_stride;
 };
 
 // NP passes of 4 (row, head) items each on one wave: the 16 lanes of a DPP row share an
@@ -401,7 +405,20 @@ __device__ unsigned long long g_stamps[2][8];
 #endif
 
 template <int G>
-__global__ __launch_bounds__(G * 64) void k_attn_fused(FusedAttnArgs a) {
+__global__ __launch_bounds__(G * 64) void k_attn_fused(FusedAttnArgs a_in) {
+  FusedAttnArgs a = a_in;
+  if (blockIdx.z) {  // uniform: request index of a ragged batch
+    const int r = blockIdx.z;
+    a.dyn += r * DFL_DYN_WORDS;
+    a.ctx_row0 += r * a.req_rows;
+    a.blk_row0 += r * a.req_rows;
+    a.kc += r * a.cache_req_stride;
+    a.vc += r * a.cache_req_stride;
+    a.out_frag += r * a.out_req_stride;
+    a.o_part += r * a.opart_req_stride;
+    a.ml_part += r * a.ml_req_stride;
+    a.tickets += r * a.n_kv;
+  }
   __shared__ __attribute__((aligned(16))) char lds_k[32 * 256];
   __shared__ __attribute__((aligned(16))) char lds_v[32 * 256];
   __shared__ __attribute__((aligned(16))) bf16_t new_k[32][128];
@@ -710,18 +727,20 @@ extern "C" int64_t dfl_attn_fused_ws_bytes(int n_q, int n_kv, int max_splits) {
   return dfl_attn_ws_bytes(n_q, max_splits) + (int64_t)n_kv * sizeof(int) + 64;
 }
 
-extern "C" int dfl_attn_fused(const float *qkv, int nsplit, int64_t split_stride, int ld, int q_col, int k_col,
-                              int v_col, int ctx_row0, int blk_row0, int n_q, int n_kv, const void *q_norm_w,
-                              const void *k_norm_w, float eps, const void *cos_tab, const void *sin_tab, int max_pos,
-                              void *kcache, void *vcache, int cache_rows, float scale, int causal,
-                              const int32_t *dyn, int kv_len_max, void *ws, int max_splits, void *out_frag,
-                              void *stream) {
+namespace {
+int attn_fused_launch(const float *qkv, int nsplit, int64_t split_stride, int ld, int q_col, int k_col, int v_col,
+                      int ctx_row0, int blk_row0, int n_q, int n_kv, const void *q_norm_w, const void *k_norm_w,
+                      float eps, const void *cos_tab, const void *sin_tab, int max_pos, void *kcache, void *vcache,
+                      int cache_rows, float scale, int causal, const int32_t *dyn, int kv_len_max, void *ws,
+                      int max_splits, void *out_frag, int R, int req_rows, int64_t cache_req_stride,
+                      int64_t out_req_stride, void *stream) {
   DFL_REQUIRE(qkv && cos_tab && sin_tab && kcache && vcache && dyn && out_frag && ws, "dfl_attn_fused: null pointer");
   DFL_REQUIRE((q_norm_w == nullptr) == (k_norm_w == nullptr), "dfl_attn_fused: give both norm weights or neither");
   DFL_REQUIRE(n_q > 0 && n_kv > 0 && n_q % n_kv == 0, "dfl_attn_fused: bad head counts");
   DFL_REQUIRE(nsplit >= 1 && ld > 0 && q_col >= 0 && k_col >= 0 && v_col >= 0 && blk_row0 >= 0 && max_pos > 0,
               "dfl_attn_fused: bad layout");
   DFL_REQUIRE(kv_len_max > 0 && kv_len_max <= cache_rows && max_splits >= 1, "dfl_attn_fused: bad kv_len_max/max_splits");
+  DFL_REQUIRE(R >= 1 && R <= 64, "dfl_attn_fused: R outside 1..64");
   // ~4 key tiles (128 keys) per split
   const int ntiles = (kv_len_max + 31) / 32;
   int ns = ntiles / 4;
@@ -752,10 +771,16 @@ extern "C" int dfl_attn_fused(const float *qkv, int nsplit, int64_t split_stride
   a.causal = causal ? 1 : 0;
   a.dyn = dyn;
   a.out_frag = (bf16x8 *)out_frag;
+  // workspace: [R] o_part | [R] ml_part | [R][n_kv] tickets
+  a.opart_req_stride = (int64_t)max_splits * n_q * 16 * 128;
+  a.ml_req_stride = (int64_t)max_splits * n_q * 16 * 2;
   a.o_part = (float *)ws;
-  a.ml_part = (float *)ws + (int64_t)max_splits * n_q * 16 * 128;
-  a.tickets = (int *)((char *)ws + dfl_attn_ws_bytes(n_q, max_splits));
-  const dim3 grid(n_kv, ns);
+  a.ml_part = (float *)ws + R * a.opart_req_stride;
+  a.tickets = (int *)((char *)ws + R * dfl_attn_ws_bytes(n_q, max_splits));
+  a.req_rows = req_rows;
+  a.cache_req_stride = cache_req_stride;
+  a.out_req_stride = out_req_stride / 8;
+  const dim3 grid(n_kv, ns, R);
   hipStream_t st = (hipStream_t)stream;
   switch (a.G) {
     case 1: hipLaunchKernelGGL(k_attn_fused<1>, grid, dim3(64), 0, st, a); break;
@@ -766,4 +791,34 @@ extern "C" int dfl_attn_fused(const float *qkv, int nsplit, int64_t split_stride
   }
   DFL_CHECK_LAUNCH("dfl_attn_fused");
   return DFL_OK;
+}
+}  // namespace
+
+extern "C" int dfl_attn_fused(const float *qkv, int nsplit, int64_t split_stride, int ld, int q_col, int k_col,
+                              int v_col, int ctx_row0, int blk_row0, int n_q, int n_kv, const void *q_norm_w,
+                              const void *k_norm_w, float eps, const void *cos_tab, const void *sin_tab, int max_pos,
+                              void *kcache, void *vcache, int cache_rows, float scale, int causal,
+                              const int32_t *dyn, int kv_len_max, void *ws, int max_splits, void *out_frag,
+                              void *stream) {
+  return attn_fused_launch(qkv, nsplit, split_stride, ld, q_col, k_col, v_col, ctx_row0, blk_row0, n_q, n_kv, q_norm_w,
+                           k_norm_w, eps, cos_tab, sin_tab, max_pos, kcache, vcache, cache_rows, scale, causal, dyn,
+                           kv_len_max, ws, max_splits, out_frag, 1, 0, 0, 0, stream);
+}
+
+extern "C" int64_t dfl_attn_fused_batch_ws_bytes(int R, int n_q, int n_kv, int max_splits) {
+  return R * (dfl_attn_ws_bytes(n_q, max_splits) + (int64_t)n_kv * sizeof(int)) + 64;
+}
+
+extern "C" int dfl_attn_fused_batch(const float *qkv, int nsplit, int64_t split_stride, int ld, int q_col, int k_col,
+                                    int v_col, int blk_row0, int req_rows, int R, int n_q, int n_kv,
+                                    const void *q_norm_w, const void *k_norm_w, float eps, const void *cos_tab,
+                                    const void *sin_tab, int max_pos, void *kcache, void *vcache, int cache_rows,
+                                    int64_t cache_req_stride, float scale, int causal, const int32_t *dyn,
+                                    int kv_len_max, void *ws, int max_splits, void *out_frag, int64_t out_req_stride,
+                                    void *stream) {
+  DFL_REQUIRE(req_rows >= 16 && out_req_stride % 8 == 0 && cache_req_stride >= (int64_t)n_kv * cache_rows * 128,
+              "dfl_attn_fused_batch: bad request strides");
+  return attn_fused_launch(qkv, nsplit, split_stride, ld, q_col, k_col, v_col, 0, blk_row0, n_q, n_kv, q_norm_w,
+                           k_norm_w, eps, cos_tab, sin_tab, max_pos, kcache, vcache, cache_rows, scale, causal, dyn,
+                           kv_len_max, ws, max_splits, out_frag, R, req_rows, cache_req_stride, out_req_stride, stream);
 }

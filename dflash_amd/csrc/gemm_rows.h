@@ -1,0 +1,101 @@
+// Pieces shared by the skinny GEMM kernels (gemm_skinny.hip: one request;
+// gemm_batch.hip: a ragged batch of requests over one weight stream).
+#pragma once
+#include "dfl_common.h"
+
+namespace {
+
+enum { EPI_F32 = 0, EPI_SILU = 1, EPI_ARGMAX = 2, EPI_RESID = 3 };
+
+struct RowSrc {
+  const bf16x8 *frag;  // mode 0: frag16 [KS][64]
+  const bf16_t *rows;  // mode 1/2: row-major [16][K], row stride ld
+  int64_t ld;
+  const float *ss;     // mode 2: [nss][16] partial sums of squares per row
+  int nss;
+  const bf16_t *nw;    // mode 2: RMSNorm weight [K]
+  float eps;
+  int valid_word;      // dyn word with the number of valid rows, < 0: all 16
+  int mode;
+};
+
+__device__ __forceinline__ bf16x8 ld_stream(const bf16x8 *p) { return __builtin_nontemporal_load(p); }
+
+// sum over the 16 lanes of a DPP row, result in each of them
+__device__ __forceinline__ float row_sum16(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+  return v;
+}
+
+// B-operand fragments of k-steps ks[0..NF) for lane l (m = l&15, kq = l>>4):
+// x[m][ks*32 + kq*8 .. +8].  `take[f]` false -> zero fragment (k-step past the wave's
+// share or past K; ks[f] is then any valid step).  The source mode is switched OUTSIDE the
+// fragment loop so that the loads of one call are issued together; branching per fragment
+// serialised them with a vmcnt(0) each (8 L2 round trips, +6.5 us per launch, measured).
+template <int NF>
+__device__ __forceinline__ void build_x(const RowSrc &s, const int (&ks)[NF], const bool (&take)[NF], int l, int nv,
+                                        float rstd, bf16x8 (&x)[NF]) {
+  const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (s.mode == 0) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) x[f] = s.frag[(size_t)ks[f] * 64 + l];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) x[f] = take[f] ? x[f] : z;
+    return;
+  }
+  const int m = l & 15, kq = l >> 4;
+  const int mr = m < nv ? m : (nv > 0 ? nv - 1 : 0);  // never read past the caller's valid rows
+  const bf16_t *row = s.rows + (int64_t)mr * s.ld + kq * 8;
+#pragma unroll
+  for (int f = 0; f < NF; ++f) x[f] = *reinterpret_cast<const bf16x8 *>(row + ks[f] * 32);
+  if (s.mode == 2) {  // Qwen3RMSNorm: weight * bf16(x * rstd), tf:modeling_qwen3.py:59-64
+    bf16x8 wv[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) wv[f] = *reinterpret_cast<const bf16x8 *>(s.nw + ks[f] * 32 + kq * 8);
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[f][j] = f2bf(bf2f(wv[f][j]) * rbf(bf2f(x[f][j]) * rstd));
+  }
+#pragma unroll
+  for (int f = 0; f < NF; ++f) x[f] = (take[f] && m < nv) ? x[f] : z;
+}
+
+// ---- host side ----
+inline int pick_ksplit_min(int KS, int fr_max) { return (KS + 16 * fr_max - 1) / (16 * fr_max); }
+
+// Workgroups along x for `ngroups` tile groups when the K axis is cut `ksplit` ways: at
+// most 256 workgroups in all (one 16-wave workgroup per CU), every workgroup walking the
+// same number of groups so that no CU streams twice as long as its neighbour.
+inline int grid_x_for(int ngroups, int ksplit = 1) {
+  int gx_max = 256 / ksplit;
+  if (gx_max < 1) gx_max = 1;
+  const int per_wg = (ngroups + gx_max - 1) / gx_max;
+  return (ngroups + per_wg - 1) / per_wg;
+}
+
+inline bool fill_src(RowSrc &d, const dfl_rows *s, int K, const char *who) {
+  if (!s) {
+    dfl_set_error("%s: null row source", who);
+    return false;
+  }
+  d.frag = (const bf16x8 *)s->frag;
+  d.rows = (const bf16_t *)s->rows;
+  d.ld = s->ld;
+  d.ss = s->ss;
+  d.nss = s->nss;
+  d.nw = (const bf16_t *)s->norm_w;
+  d.eps = s->eps;
+  d.valid_word = s->valid_word;
+  d.mode = s->mode;
+  const bool ok = (s->mode == 0 && s->frag) || (s->mode == 1 && s->rows && s->ld >= K && s->ld % 8 == 0) ||
+                  (s->mode == 2 && s->rows && s->ss && s->nss >= 1 && s->norm_w && s->ld >= K && s->ld % 8 == 0);
+  if (!ok) dfl_set_error("%s: bad row source (mode %d)", who, s->mode);
+  return ok;
+}
+
+
+}  // namespace

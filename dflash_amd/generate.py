@@ -112,6 +112,10 @@ class DecodeSession:
         self.hook_calls = 0
         self.stopped = False
         self.events = None  # set to a dict to have cycle() record (start, end) event pairs per phase
+        # the tapped rows live here from a verify to the next draft (own buffer: several
+        # sessions may be interleaved on one NativeTarget)
+        self.taps_buf = (torch.zeros(16, len(model.target_layer_ids) * model.config.hidden_size, dtype=torch.bfloat16,
+                                     device=dev) if (self.native and self.use_draft) else None)
 
     @torch.inference_mode()
     def prefill(self) -> None:
@@ -189,7 +193,8 @@ class DecodeSession:
         if self.native:
             posterior, taps = self.target.verify(
                 blk[0], start, self.tcache, temperature=self.temperature,
-                tap_layers=self.model.target_layer_ids if (want_hidden and self.use_draft) else ())
+                tap_layers=self.model.target_layer_ids if (want_hidden and self.use_draft) else (),
+                taps_out=self.taps_buf)
             self._mark("target", 1)
         else:
             out = self.target(blk, position_ids=self.position_ids[:, start:start + bs],

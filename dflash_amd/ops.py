@@ -251,3 +251,147 @@ def accept_commit(block_ids, posterior, bs: int, output_ids, dyn, stop_ids=None,
                                   _p(stop_ids, I64, "stop_ids") if n_stop else None, n_stop, _p(result, I32, "result"),
                                   _stream()),
           "dfl_accept_commit")
+
+
+# ---- ragged batch of requests (include/dflash_hip.h, second half) ---------------------------
+from ._lib import RowsBatch  # noqa: E402
+
+
+def batch_tiles(R: int) -> int:
+    return lib().dfl_batch_tiles(R)
+
+
+def batch_ksplit(K: int) -> int:
+    return lib().dfl_batch_ksplit(K)
+
+
+class BatchRowSource:
+    def __init__(self, struct: RowsBatch, *keep):
+        self.struct, self.keep = struct, keep
+
+    @property
+    def ref(self):
+        return _C.byref(self.struct)
+
+
+def brows_frag(frag: torch.Tensor) -> BatchRowSource:
+    """frag [MT, 16*K] bf16: request r's frag16 buffer is frag[r]."""
+    assert frag.dim() == 2 and frag.is_contiguous()
+    r0 = Rows(_p(frag, BF16, "frag"), None, 0, None, 0, None, 0.0, -1, 0)
+    return BatchRowSource(RowsBatch(r0, frag.stride(0), 0, 0), frag)
+
+
+def brows_plain(rows: torch.Tensor, valid_word: int = -1) -> BatchRowSource:
+    """rows [MT, 16, K] bf16 (unit inner stride)."""
+    assert rows.is_cuda and rows.dtype == BF16 and rows.dim() == 3 and rows.stride(2) == 1
+    r0 = Rows(None, rows.data_ptr(), rows.stride(1), None, 0, None, 0.0, valid_word, 1)
+    return BatchRowSource(RowsBatch(r0, 0, rows.stride(0), 0), rows)
+
+
+def brows_normed(rows: torch.Tensor, ss: torch.Tensor, nss: int, norm_w: torch.Tensor, eps: float,
+                 valid_word: int = -1) -> BatchRowSource:
+    """rows [MT, 16, K] + ss [MT, >= nss*16]: the GEMM applies the RMSNorm per request."""
+    assert rows.is_cuda and rows.dtype == BF16 and rows.dim() == 3 and rows.stride(2) == 1
+    assert ss.dim() == 2 and ss.shape[1] >= nss * 16 and ss.stride(1) == 1
+    r0 = Rows(None, rows.data_ptr(), rows.stride(1), _p(ss[0], F32, "ss"), nss, _p(norm_w, BF16, "norm_w"), eps,
+              valid_word, 2)
+    return BatchRowSource(RowsBatch(r0, 0, rows.stride(0), ss.stride(0)), rows, ss, norm_w)
+
+
+def gemm_batch_ws(N: int, K: int, device) -> torch.Tensor:
+    return torch.zeros(lib().dfl_gemm_batch_ws_bytes(N, K), dtype=torch.uint8, device=device)
+
+
+def gemm_f32_batch(wp, x: BatchRowSource, R: int, N: int, K: int, out: torch.Tensor, dyn) -> None:
+    assert out.numel() >= batch_ksplit(K) * batch_tiles(R) * 16 * N
+    check(lib().dfl_gemm_f32_batch(_p(wp, BF16, "wp"), x.ref, R, N, K, _p(out, F32, "out"), _p(dyn, I32, "dyn"),
+                                   _stream()), "dfl_gemm_f32_batch")
+
+
+def gemm_silu_mul_batch(wp_gu, x: BatchRowSource, R: int, I: int, K: int, act: torch.Tensor, ws, dyn) -> None:
+    assert act.dim() == 2 and act.shape[1] >= 16 * I and act.shape[0] >= batch_tiles(R)
+    check(lib().dfl_gemm_silu_mul_batch(_p(wp_gu, BF16, "wp_gu"), x.ref, R, I, K, _p(act, BF16, "act"), act.stride(0),
+                                        _p(ws), _p(dyn, I32, "dyn"), _stream()), "dfl_gemm_silu_mul_batch")
+
+
+def gemm_resid_batch(wp, x: BatchRowSource, R: int, N: int, K: int, h_io: torch.Tensor, *, add_residual: bool,
+                     ws, dyn, ss_out=None, tap=None) -> None:
+    """h_io [MT, 16, >=N]; tap: optional [MT, 16, *] view; ss_out [MT, >=N]."""
+    assert h_io.is_cuda and h_io.dtype == BF16 and h_io.dim() == 3 and h_io.stride(2) == 1
+    tp, ldt, tst = None, 0, 0
+    if tap is not None:
+        assert tap.is_cuda and tap.dtype == BF16 and tap.dim() == 3 and tap.stride(2) == 1
+        tp, ldt, tst = tap.data_ptr(), tap.stride(1), tap.stride(0)
+    sp, sst = None, 0
+    if ss_out is not None:
+        assert ss_out.dim() == 2 and ss_out.shape[1] >= N and ss_out.dtype == F32
+        sp, sst = ss_out.data_ptr(), ss_out.stride(0)
+    check(lib().dfl_gemm_resid_batch(_p(wp, BF16, "wp"), x.ref, R, N, K, h_io.data_ptr(), h_io.stride(1),
+                                     h_io.stride(0), int(add_residual), tp, ldt, tst, sp, sst, _p(ws),
+                                     _p(dyn, I32, "dyn"), _stream()), "dfl_gemm_resid_batch")
+
+
+def gemm_argmax_batch(wp, x: BatchRowSource, R: int, V: int, K: int, row0: int, nrows: int, ws,
+                      out_ids: torch.Tensor, out_off: int, dyn, nrows_dyn_word: int = -1,
+                      logits: Optional[torch.Tensor] = None) -> None:
+    """out_ids int64 [MT, n]: ids of request r's rows row0.. at out_ids[r, out_off..]."""
+    assert out_ids.dim() == 2 and out_ids.dtype == I64 and out_ids.stride(1) == 1
+    lp, lst = None, 0
+    if logits is not None:
+        assert logits.dim() == 3 and logits.shape[1] == 16 and logits.shape[2] == V and logits.is_contiguous()
+        lp, lst = _p(logits, BF16, "logits"), logits.stride(0)
+    check(lib().dfl_gemm_argmax_batch(_p(wp, BF16, "wp"), x.ref, R, V, K, row0, nrows, _p(dyn, I32, "dyn"),
+                                      nrows_dyn_word, _p(ws), out_ids.data_ptr(), out_ids.stride(0), out_off, lp, lst,
+                                      _stream()), "dfl_gemm_argmax_batch")
+
+
+def embed_rows_batch(embed, ids: torch.Tensor, R: int, h_out: torch.Tensor, H: int, ss_out: torch.Tensor, dyn,
+                     dyn_word: int) -> None:
+    assert ids.dim() == 2 and ids.dtype == I64 and ids.stride(1) == 1 and h_out.dim() == 3 and ss_out.dim() == 2
+    check(lib().dfl_embed_rows_batch(_p(embed, BF16, "embed"), ids.data_ptr(), ids.stride(0), R, h_out.data_ptr(),
+                                     h_out.stride(0), H, ss_out.data_ptr(), ss_out.stride(0), _p(dyn, I32, "dyn"),
+                                     dyn_word, _stream()), "dfl_embed_rows_batch")
+
+
+def kv_append_batch(*, kv, nsplit, split_stride, ld, k_col, v_col, col_layer_stride, n_layers, R, n_kv, k_norm_w,
+                    eps, cos_tab, sin_tab, kcache, vcache, dyn) -> None:
+    """kcache/vcache [MT, L, n_kv, rows, 128]; k_norm_w [L, 128] or None."""
+    assert kcache.shape == vcache.shape and kcache.dim() == 5 and kcache.shape[4] == 128 and kcache.is_contiguous()
+    check(lib().dfl_kv_append_batch(
+        _p(kv, F32, "kv"), nsplit, split_stride, ld, k_col, v_col, col_layer_stride, n_layers, R, 16, n_kv,
+        _p(k_norm_w, BF16, "k_norm_w"), 128, eps, _p(cos_tab, BF16, "cos"), _p(sin_tab, BF16, "sin"),
+        cos_tab.shape[0], _p(kcache, BF16, "kcache"), _p(vcache, BF16, "vcache"), kcache.shape[3],
+        kcache.stride(0), kcache.stride(1), _p(dyn, I32, "dyn"), _stream()), "dfl_kv_append_batch")
+
+
+def attn_fused_batch_ws(R: int, n_q: int, n_kv: int, max_splits: int, device) -> torch.Tensor:
+    return torch.zeros(lib().dfl_attn_fused_batch_ws_bytes(R, n_q, n_kv, max_splits), dtype=torch.uint8,
+                       device=device)
+
+
+def attn_fused_batch(*, qkv, nsplit, split_stride, ld, q_col, k_col, v_col, R, n_q, n_kv, q_norm_w, k_norm_w, eps,
+                     cos_tab, sin_tab, kcache, vcache, layer: int, scale, causal: bool, dyn, kv_len_max, ws,
+                     max_splits, out_frag) -> None:
+    """kcache/vcache [MT, L, n_kv, rows, 128] (layer `layer` is used); out_frag [MT, 16*n_q*128]."""
+    assert kcache.shape == vcache.shape and kcache.dim() == 5 and kcache.shape[4] == 128 and kcache.is_contiguous()
+    assert out_frag.dim() == 2 and out_frag.is_contiguous()
+    kc, vc = kcache[0, layer], vcache[0, layer]
+    check(lib().dfl_attn_fused_batch(
+        _p(qkv, F32, "qkv"), nsplit, split_stride, ld, q_col, k_col, v_col, 0, 16, R, n_q, n_kv,
+        _p(q_norm_w, BF16, "q_norm_w"), _p(k_norm_w, BF16, "k_norm_w"), eps, _p(cos_tab, BF16, "cos"),
+        _p(sin_tab, BF16, "sin"), cos_tab.shape[0], kc.data_ptr(), vc.data_ptr(), kcache.shape[3], kcache.stride(0),
+        scale, int(causal), _p(dyn, I32, "dyn"), kv_len_max, _p(ws), max_splits, _p(out_frag, BF16, "out_frag"),
+        out_frag.stride(0), _stream()), "dfl_attn_fused_batch")
+
+
+def accept_commit_batch(block: torch.Tensor, posterior: torch.Tensor, R: int, output_ids: torch.Tensor, dyn_d, dyn_t,
+                        stop_ids, result: torch.Tensor, rearm_mask_id: Optional[int] = None) -> None:
+    """block/posterior int64 [MT, 16]; output_ids int64 [MT, n]; result int32 [MT, 4]."""
+    assert block.dim() == 2 and posterior.dim() == 2 and output_ids.dim() == 2
+    n_stop = 0 if stop_ids is None else stop_ids.numel()
+    check(lib().dfl_accept_commit_batch(
+        _p(block, I64, "block"), block.stride(0), _p(posterior, I64, "posterior"), posterior.stride(0), R,
+        _p(output_ids, I64, "output_ids"), output_ids.stride(0), output_ids.shape[1], _p(dyn_d, I32, "dyn_d"),
+        _p(dyn_t, I32, "dyn_t"), _p(stop_ids, I64, "stop_ids") if n_stop else None, n_stop,
+        _p(result, I32, "result"), block.data_ptr() if rearm_mask_id is not None else None,
+        int(rearm_mask_id) if rearm_mask_id is not None else 0, _stream()), "dfl_accept_commit_batch")

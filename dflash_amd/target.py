@@ -170,10 +170,13 @@ class NativeTarget:
     # ---- the verify forward on the kernels
     @torch.inference_mode()
     def verify(self, block_ids: torch.Tensor, start: int, cache: TargetKVCache, *, tap_layers: Sequence[int] = (),
-               temperature: float = 0.0, logits_out: Optional[torch.Tensor] = None):
+               temperature: float = 0.0, logits_out: Optional[torch.Tensor] = None,
+               taps_out: Optional[torch.Tensor] = None):
         """block_ids int64 [bs] at positions start..start+bs-1 (cache rows alike).
         Returns (posterior ids int64 [1, bs], taps bf16 [16, len(tap_layers)*H] or None).
-        K/V of all bs rows are written; the caller crops to what it accepts."""
+        K/V of all bs rows are written; the caller crops to what it accepts.
+        taps_out: the caller's own [16, len(tap_layers)*H] buffer (a decode session keeps the
+        rows until its next draft; sessions interleaved on one target must not share one)."""
         bs = block_ids.numel()
         if bs < 1 or bs > 16:
             raise ValueError("verify takes 1..16 block rows")
@@ -191,9 +194,14 @@ class NativeTarget:
             if max(tap_layers) >= self.L - 1:
                 raise NotImplementedError("tapping the last layer (post-norm state) is not supported")
             key = len(tap_layers)
-            if key not in self._taps:
-                self._taps[key] = torch.zeros(16, key * H, dtype=BF16, device=self._dev)
-            taps = self._taps[key]
+            if taps_out is not None:
+                if taps_out.shape != (16, key * H) or taps_out.dtype != BF16 or not taps_out.is_contiguous():
+                    raise ValueError("taps_out must be a contiguous bf16 [16, len(tap_layers)*H] tensor")
+                taps = taps_out
+            else:
+                if key not in self._taps:
+                    self._taps[key] = torch.zeros(16, key * H, dtype=BF16, device=self._dev)
+                taps = self._taps[key]
         Ls, src = self.layers, self.src
         ops.embed_rows(self.embed, block_ids, ws["h"], H, ws["ss_emb"], dyn, ops.DYN_BS)
         for i, lw in enumerate(Ls):

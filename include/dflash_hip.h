@@ -211,6 +211,88 @@ int dfl_accept_commit(const int64_t *block_ids, const int64_t *posterior, int bs
                       int64_t output_len, int32_t *dyn, const int64_t *stop_ids, int n_stop, int32_t *result,
                       void *stream);
 
+/* ======================================================================================
+ * Ragged batch of requests on one GPU (BASELINE.json configs[2]; SURVEY.md §8e: "within a
+ * GPU the requests are a ragged batch for the kernels: shared weight stream, per-request
+ * S and tau").  The reference has no batched form of the path — "batch" there is a Python
+ * loop over prompts (benchmark_batched.py:212-243, benchmark.py:445) — so these entry
+ * points replace R consecutive passes of model/dflash.py:235-268 by one pass in which the
+ * R requests share every weight byte.  Request r (0 <= r < R <= 4 per launch):
+ *   - 16-row tile at `base + r * stride` of every activation buffer,
+ *   - lengths at dyn + r * DFL_DYN_WORDS,
+ *   - KV cache at cache + r * cache_req_stride.
+ * The GEMMs are compiled for 2 or 4 tiles: buffers (and dyn) must hold dfl_batch_tiles(R)
+ * requests; the unused ones need valid (readable) memory and dyn words of zero.
+ * ====================================================================================== */
+typedef struct dfl_rows_batch {
+  dfl_rows r0;          /* request 0, as for the single-request GEMMs */
+  int64_t frag_stride;  /* bf16 elements between the requests' frag16 buffers (mode 0), %8 == 0 */
+  int64_t rows_stride;  /* bf16 elements between the requests' row buffers (mode 1, 2) */
+  int64_t ss_stride;    /* floats between the requests' sum-of-squares partials (mode 2) */
+} dfl_rows_batch;
+
+int dfl_batch_tiles(int R);  /* 2 for R <= 2, else 4 */
+int dfl_batch_ksplit(int K); /* K parts of 2048 the batched GEMMs cut K into (grid.y) */
+/* workspace of the fused-epilogue batched GEMMs: arrival tickets (ZEROED once by the caller,
+ * left zero by every launch), argmax candidates, fp32 partial tiles of the K parts */
+int64_t dfl_gemm_batch_ws_bytes(int N, int K);
+
+/* dfl_gemm_f32 for R requests: out[c][r*16+m][n], c < dfl_batch_ksplit(K) partial sums
+ * (out holds ksplit * dfl_batch_tiles(R) * 16 * N floats). */
+int dfl_gemm_f32_batch(const void *wp, const dfl_rows_batch *x, int R, int N, int K, float *out, const int32_t *dyn,
+                       void *stream);
+/* dfl_gemm_silu_mul for R requests; request r's frag16 output at act_frag + r * act_stride. */
+int dfl_gemm_silu_mul_batch(const void *wp_gateup, const dfl_rows_batch *x, int R, int I, int K, void *act_frag,
+                            int64_t act_stride, void *ws, const int32_t *dyn, void *stream);
+/* dfl_gemm_resid for R requests (h_io, tap, ss_out advance by their strides per request). */
+int dfl_gemm_resid_batch(const void *wp, const dfl_rows_batch *x, int R, int N, int K, void *h_io, int64_t ldh,
+                         int64_t h_stride, int add_residual, void *tap, int64_t ldtap, int64_t tap_stride,
+                         float *ss_out, int64_t ss_stride, void *ws, const int32_t *dyn, void *stream);
+/* dfl_gemm_argmax for R requests: out_ids[r * out_stride + out_off + (row - row0)]. */
+int dfl_gemm_argmax_batch(const void *wp, const dfl_rows_batch *x, int R, int V, int K, int row0, int nrows,
+                          const int32_t *dyn, int nrows_dyn_word, void *ws, int64_t *out_ids, int64_t out_stride,
+                          int out_off, void *logits, int64_t logits_stride, void *stream);
+/* dfl_embed_rows for R requests: ids[r * ids_stride + m]. */
+int dfl_embed_rows_batch(const void *embed, const int64_t *ids, int64_t ids_stride, int R, void *h_out,
+                         int64_t h_stride, int H, float *ss_out, int64_t ss_stride, const int32_t *dyn, int dyn_word,
+                         void *stream);
+
+/* Context K/V of ALL draft layers for R requests in one launch (model/dflash.py:73-85, the
+ * context half): kv = fp32 partials of the context rows times the concatenated k/v weights
+ * of the n_layers layers (layer i's k columns at k_col + i * col_layer_stride, v alike);
+ * k_norm + RoPE (position pos0 + row) -> caches at rows S + row, row < dyn tau.  The block
+ * stage that follows then sees them as cached rows (lengths in block form, see
+ * dfl_accept_commit_batch). */
+int dfl_kv_append_batch(const float *kv, int nsplit, int64_t split_stride, int ld, int k_col, int v_col,
+                        int col_layer_stride, int n_layers, int R, int req_rows, int n_kv, const void *k_norm_w,
+                        int64_t kw_layer_stride, float eps, const void *cos_tab, const void *sin_tab, int max_pos,
+                        void *kcache, void *vcache, int cache_rows, int64_t cache_req_stride,
+                        int64_t cache_layer_stride, const int32_t *dyn, void *stream);
+
+/* dfl_attn_fused for R requests (grid.z = request): request r's block rows at partial-buffer
+ * rows blk_row0 + r * req_rows, cache at + r * cache_req_stride, frag16 output at
+ * + r * out_req_stride; no context rows in this form (dyn tau == 0).
+ * ws: dfl_attn_fused_batch_ws_bytes bytes, zeroed once. */
+int64_t dfl_attn_fused_batch_ws_bytes(int R, int n_q, int n_kv, int max_splits);
+int dfl_attn_fused_batch(const float *qkv, int nsplit, int64_t split_stride, int ld, int q_col, int k_col, int v_col,
+                         int blk_row0, int req_rows, int R, int n_q, int n_kv, const void *q_norm_w,
+                         const void *k_norm_w, float eps, const void *cos_tab, const void *sin_tab, int max_pos,
+                         void *kcache, void *vcache, int cache_rows, int64_t cache_req_stride, float scale, int causal,
+                         const int32_t *dyn, int kv_len_max, void *ws, int max_splits, void *out_frag,
+                         int64_t out_req_stride, void *stream);
+
+/* dfl_accept_commit for R requests, one wavefront each (model/dflash.py:258-268 per request).
+ * bs is read from dyn_d.  Updates dyn_d (draft form: S <- start, tau <- acc+1, pos0 <- start,
+ * start <- start+acc+1) and dyn_t (block form: S = pos0 = start = new start, tau = 0), the
+ * latter read by the target verify and by the draft's block stage of the next cycle.
+ * result int32 [R][4] = {acc, new_start, stop, cycle}.  A request with dyn_d bs == 0 is idle.
+ * next_block (optional, may alias block_ids; same stride): re-armed for the next cycle as
+ * [bonus token, mask_id x 15] = output_ids[new start .. +16) (model/dflash.py:235). */
+int dfl_accept_commit_batch(const int64_t *block_ids, int64_t blk_stride, const int64_t *posterior,
+                            int64_t post_stride, int R, int64_t *output_ids, int64_t out_stride, int64_t output_len,
+                            int32_t *dyn_d, int32_t *dyn_t, const int64_t *stop_ids, int n_stop, int32_t *result,
+                            int64_t *next_block, int64_t mask_id, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
