@@ -103,6 +103,9 @@ def gpu_leg(args, rank, world, dev):
     torch.cuda.synchronize()
     log(f"[rank {rank}] models ready in {time.time() - t0:.1f}s")
 
+    if args.requests_per_gpu > 1:
+        return batched_leg(args, rank, dev, draft, target, perm, cfg)
+
     bs, P = 16, args.prefix
     prompt = torch.randint(0, 151000, (1, P), generator=torch.Generator().manual_seed(1 + rank)).to(dev)
     ncyc = args.warmup + args.steps + 1
@@ -176,6 +179,81 @@ def gpu_leg(args, rank, world, dev):
         hot_path={"draft_plus_lm_head_ms_per_cycle": draft_ms, "target_verify_ms_per_cycle": target_ms,
                   "algorithmic_bytes_per_cycle": hot_bytes,
                   "achieved_GBps": hot_bytes / (draft_ms * 1e-3) / 1e9,
+                  "frac_of_8TBps": hot_bytes / (draft_ms * 1e-3) / 1e9 / 8000.0},
+    )
+
+
+def batched_leg(args, rank, dev, draft, target, perm, cfg):
+    """--requests-per-gpu R > 1 (BASELINE.json configs[2]: 4 requests per GPU): the R requests of
+    this rank advance together, one pass over the weights per cycle (dflash_amd.batch)."""
+    from dflash_amd import distributed as D
+    from dflash_amd.batch import BatchedDecoder
+    from dflash_amd.synthetic import greedy_walk
+    R, bs, P = args.requests_per_gpu, 16, args.prefix
+    ncyc = args.warmup + args.steps + 1
+    plans = [tau_plan(ncyc + 8, bs, seed=100 + rank * 16 + r) for r in range(R)]
+    need = max(sum(k + 1 for k in pl[:ncyc]) for pl in plans) + 2 * bs
+    prompts = [torch.randint(0, 151000, (1, P), generator=torch.Generator().manual_seed(1 + rank * 16 + r)).to(dev)
+               for r in range(R)]
+    Gs = [greedy_walk(perm, p, need + 2 * bs).to(dev) for p in prompts]
+    dec = BatchedDecoder(draft, target, R, max_rows=P + need + 3 * bs, out_len=P + need + bs,
+                         mask_token_id=cfg.mask_token_id)
+    for r, p in enumerate(prompts):
+        dec.admit(r, p)
+
+    def hook(r, blk, start, call):
+        k, G = plans[r][call], Gs[r]
+        if k:
+            blk[0, 1:k + 1] = G[start + 1:start + k + 1]
+        if k + 1 < bs:
+            wrong = G[start + k + 1]
+            blk[0, k + 1] = torch.where(blk[0, k + 1] == wrong, (wrong + 1) % 151000, blk[0, k + 1])
+
+    dec.cycle(hook)
+    for _ in range(args.warmup):
+        dec.cycle(hook)
+    ev_all = []
+    if torch.distributed.is_initialized():
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tokens = 0
+    for _ in range(args.steps):
+        dec.events = {}
+        out = dec.cycle(hook)
+        ev_all.append(dec.events)
+        tokens += sum(o[0] for o in out)
+    torch.cuda.synchronize()
+    if torch.distributed.is_initialized():
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    dec.events = None
+
+    def avg_ms(key):
+        return sum(e[key][0].elapsed_time(e[key][1]) for e in ev_all) / len(ev_all)
+
+    lm_ms, draft_ms, target_ms = avg_ms("lm_head"), avg_ms("draft"), avg_ms("target")
+    n_ok = n_all = 0
+    for r in range(R):
+        n_ok += int((dec.output_ids[r, P:dec.start[r]] == Gs[r][P:dec.start[r]]).sum())
+        n_all += dec.start[r] - P
+    dt_max, tok_sum = D.reduce_timing(dt, float(tokens), device=dev)
+    _, cyc_sum = D.reduce_timing(dt, float(args.steps * R), device=dev)
+    # lm_head launch: weights once + the fp32 partial tiles of the 2 K parts written and read back
+    part = 2 * (151936 // 16) * 4 * 1024 * 2
+    kv_bytes = 20480 * (P + 16)
+    hot_bytes = DRAFT_WEIGHT_BYTES + LM_HEAD_BYTES + R * kv_bytes
+    return dict(
+        value=tok_sum / dt_max, ms_per_step=1000.0 * dt_max / args.steps, mean_tau=tok_sum / cyc_sum,
+        raw_tau1_value=cyc_sum / dt_max, lossless_fraction=n_ok / max(1, n_all),
+        roofline={"kernel": "k_gemm_b<4,EPI_ARGMAX> (lm_head GEMM + fused argmax, 4 request tiles)", "bound": "hbm",
+                  "achieved": LM_HEAD_BYTES / (lm_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                  "frac": LM_HEAD_BYTES / (lm_ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
+                  "bytes_per_launch": LM_HEAD_BYTES, "avg_ms": lm_ms,
+                  "note": f"algorithmic bytes = the weights; the kernel also moves {part} B of fp32 partial tiles "
+                          "(K parts meet through HBM)"},
+        hot_path={"draft_plus_lm_head_ms_per_cycle": draft_ms, "target_verify_ms_per_cycle": target_ms,
+                  "algorithmic_bytes_per_cycle": hot_bytes, "achieved_GBps": hot_bytes / (draft_ms * 1e-3) / 1e9,
                   "frac_of_8TBps": hot_bytes / (draft_ms * 1e-3) / 1e9 / 8000.0},
     )
 
@@ -262,6 +340,9 @@ def main():
     ap.add_argument("--target-layers", type=int, default=36)
     ap.add_argument("--cpu-cycles", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--requests-per-gpu", type=int, default=1,
+                    help="R > 1: R requests per GPU decode as one ragged batch sharing the weight stream "
+                         "(BASELINE.json configs[2] uses 4); needs the native verify")
     ap.add_argument("--hf-verify", action="store_true",
                     help="verify through the HF/PyTorch target forward (round-1 configuration) instead of "
                          "dflash_amd.NativeTarget")
@@ -294,9 +375,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "Qwen3-8B-shaped target (" + ("HF/PyTorch-ROCm verify" if args.hf_verify else
                                    "HF prefill, NativeTarget verify on the kernels") + ") + DFlash-b16 5-layer draft, "
-                                   f"block=16, temp=0, batch=1 per GPU, prefix={args.prefix}, random-init weights, "
+                                   f"block=16, temp=0, batch={args.requests_per_gpu} per GPU, prefix={args.prefix}, random-init weights, "
                                    "scripted acceptance (seeded truncated-geometric, mean tau 7.3 per 20-cycle block)",
-                       "target_layers": args.target_layers, "requests": world,
+                       "target_layers": args.target_layers, "requests": world * args.requests_per_gpu,
                        "target_verify": "hf" if args.hf_verify else "native", "parallelism": f"dp{world}"},
             "mean_acceptance_length": res["mean_tau"], "raw_tau1_value": res["raw_tau1_value"],
             "lossless_fraction": res["lossless_fraction"], "roofline": res["roofline"], "hot_path": res["hot_path"],

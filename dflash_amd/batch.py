@@ -80,8 +80,8 @@ class BatchedDecoder:
         self.nqkv_d = c.q_dim + 2 * c.kv_dim
         self.nkv_all = Ld * 2 * c.kv_dim
         ks = ops.batch_ksplit
-        self.d = dict(h=z(MT, 16, H), ctxh=z(MT, 16, H), ss_emb=z(MT, 16, dt=F32), ss_h=z(MT, H, dt=F32),
-                      ss_ctx=z(MT, H, dt=F32), attn=z(MT, 16 * c.q_dim), act=z(MT, 16 * I),
+        self.d = dict(h=z(MT, 16, H), ctxh=z(MT, 16, H), ss_emb=z(MT, 16, dt=F32), xn=z(MT, 16 * H),
+                      attn=z(MT, 16 * c.q_dim), act=z(MT, 16 * I),
                       part_qkv=z(ks(H) * MT * 16 * self.nqkv_d, dt=F32), part_kv=z(ks(H) * MT * 16 * self.nkv_all, dt=F32),
                       taps=z(MT, 16, c.fc_in))
         # context K/V weights of all layers as ONE packed weight: the k/v column tiles of each
@@ -91,7 +91,7 @@ class BatchedDecoder:
         self.k_norm_all = torch.stack([lw["k_norm"] for lw in L]).contiguous()
         # ---- target scratch
         self.nqkv_t = t.nqkv
-        self.t = dict(h=z(MT, 16, H), ss_emb=z(MT, 16, dt=F32), ss_h=z(MT, H, dt=F32), attn=z(MT, 16 * t.q_dim),
+        self.t = dict(h=z(MT, 16, H), ss_emb=z(MT, 16, dt=F32), xn=z(MT, 16 * H), attn=z(MT, 16 * t.q_dim),
                       act=z(MT, 16 * t.I), part_qkv=z(ks(H) * MT * 16 * t.nqkv, dt=F32))
         # ---- shared workspaces (launches are stream-ordered)
         nmax = max(c.vocab_size, t.V, 2 * I, 2 * t.I)
@@ -102,22 +102,12 @@ class BatchedDecoder:
         self.aws_d = ops.attn_fused_batch_ws(MT, c.num_attention_heads, c.num_key_value_heads, max_splits, dev)
         self.aws_t = ops.attn_fused_batch_ws(MT, t.n_q, t.n_kv, max_splits, dev)
         # ---- row sources
-        eps, nt = c.rms_norm_eps, H // 16
+        # (normalised operands come from dfl_norm_frag_batch: at 4 tiles the in-GEMM norm of the
+        # single-request path, replicated in every workgroup, costs more than that launch)
         d, tt = self.d, self.t
-        self.src_d = dict(
-            taps=ops.brows_plain(d["taps"], ops.DYN_TAU),
-            ctx=ops.brows_normed(d["ctxh"], d["ss_ctx"], nt, model.w["hidden_norm"], eps, ops.DYN_TAU),
-            ln1=[ops.brows_normed(d["h"], d["ss_emb"] if i == 0 else d["ss_h"], 1 if i == 0 else nt, lw["ln1"], eps,
-                                  ops.DYN_BS) for i, lw in enumerate(L)],
-            ln2=[ops.brows_normed(d["h"], d["ss_h"], nt, lw["ln2"], eps, ops.DYN_BS) for lw in L],
-            final=ops.brows_normed(d["h"], d["ss_h"], nt, model.w["norm"], eps, ops.DYN_BS),
-            attn=ops.brows_frag(d["attn"]), act=ops.brows_frag(d["act"]))
-        self.src_t = dict(
-            ln1=[ops.brows_normed(tt["h"], tt["ss_emb"] if i == 0 else tt["ss_h"], 1 if i == 0 else nt, lw["ln1"],
-                                  t.eps, ops.DYN_BS) for i, lw in enumerate(t.layers)],
-            ln2=[ops.brows_normed(tt["h"], tt["ss_h"], nt, lw["ln2"], t.eps, ops.DYN_BS) for lw in t.layers],
-            final=ops.brows_normed(tt["h"], tt["ss_h"], nt, t.norm, t.eps, ops.DYN_BS),
-            attn=ops.brows_frag(tt["attn"]), act=ops.brows_frag(tt["act"]))
+        self.src_d = dict(taps=ops.brows_plain(d["taps"], ops.DYN_TAU), xn=ops.brows_frag(d["xn"]),
+                          attn=ops.brows_frag(d["attn"]), act=ops.brows_frag(d["act"]))
+        self.src_t = dict(xn=ops.brows_frag(tt["xn"]), attn=ops.brows_frag(tt["attn"]), act=ops.brows_frag(tt["act"]))
         self.lm_wp = None
         self.embed_w = None
         # ---- host mirror of the lengths
@@ -126,6 +116,13 @@ class BatchedDecoder:
         self.live = [False] * R
         self.hook_calls = [0] * R
         self.bs = [16] * R
+        self.events = None  # set to a dict to have cycle() record (start, end) event pairs per phase
+
+    def _mark(self, key, which):
+        if self.events is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.events.setdefault(key, [None, None])[which] = e
 
     # ------------------------------------------------------------------ admission
     @torch.inference_mode()
@@ -191,9 +188,11 @@ class BatchedDecoder:
         cos, sin = m._rope_tab(kvmax + 64)
         ops.embed_rows_batch(self.embed_w, self.block, R, d["h"], H, d["ss_emb"], self.dyn_t, ops.DYN_BS)
         # context rows: fc, then K/V of all layers appended to the draft caches
+        eps = c.rms_norm_eps
         ops.gemm_resid_batch(m.w["fc"], s["taps"], R, H, c.fc_in, d["ctxh"], add_residual=False, ws=self.gws,
-                             dyn=self.dyn_d, ss_out=d["ss_ctx"])
-        ops.gemm_f32_batch(self.kv_all, s["ctx"], R, self.nkv_all, H, d["part_kv"], self.dyn_d)
+                             dyn=self.dyn_d)
+        ops.norm_frag_batch(d["ctxh"], R, m.w["hidden_norm"], eps, d["xn"], self.dyn_d, ops.DYN_TAU)
+        ops.gemm_f32_batch(self.kv_all, s["xn"], R, self.nkv_all, H, d["part_kv"], self.dyn_d)
         nsp = ops.batch_ksplit(H)
         ops.kv_append_batch(kv=d["part_kv"], nsplit=nsp, split_stride=MT * 16 * self.nkv_all, ld=self.nkv_all, k_col=0,
                             v_col=c.kv_dim, col_layer_stride=2 * c.kv_dim, n_layers=c.num_hidden_layers, R=R,
@@ -201,7 +200,8 @@ class BatchedDecoder:
                             sin_tab=sin, kcache=self.dk, vcache=self.dv, dyn=self.dyn_d)
         # block rows
         for i, lw in enumerate(L):
-            ops.gemm_f32_batch(lw["qkv"], s["ln1"][i], R, self.nqkv_d, H, d["part_qkv"], self.dyn_t)
+            ops.norm_frag_batch(d["h"], R, lw["ln1"], eps, d["xn"], self.dyn_t, ops.DYN_BS)
+            ops.gemm_f32_batch(lw["qkv"], s["xn"], R, self.nqkv_d, H, d["part_qkv"], self.dyn_t)
             ops.attn_fused_batch(qkv=d["part_qkv"], nsplit=nsp, split_stride=MT * 16 * self.nqkv_d, ld=self.nqkv_d,
                                  q_col=0, k_col=c.q_dim, v_col=c.q_dim + c.kv_dim, R=R, n_q=c.num_attention_heads,
                                  n_kv=c.num_key_value_heads, q_norm_w=lw["q_norm"], k_norm_w=lw["k_norm"],
@@ -209,12 +209,16 @@ class BatchedDecoder:
                                  scale=c.head_dim ** -0.5, causal=False, dyn=self.dyn_t, kv_len_max=kvmax,
                                  ws=self.aws_d, max_splits=self.max_splits, out_frag=d["attn"])
             ops.gemm_resid_batch(lw["o"], s["attn"], R, H, c.q_dim, d["h"], add_residual=True, ws=self.gws,
-                                 dyn=self.dyn_t, ss_out=d["ss_h"])
-            ops.gemm_silu_mul_batch(lw["gu"], s["ln2"][i], R, I, H, d["act"], self.gws, self.dyn_t)
+                                 dyn=self.dyn_t)
+            ops.norm_frag_batch(d["h"], R, lw["ln2"], eps, d["xn"], self.dyn_t, ops.DYN_BS)
+            ops.gemm_silu_mul_batch(lw["gu"], s["xn"], R, I, H, d["act"], self.gws, self.dyn_t)
             ops.gemm_resid_batch(lw["down"], s["act"], R, H, I, d["h"], add_residual=True, ws=self.gws,
-                                 dyn=self.dyn_t, ss_out=d["ss_h"])
-        ops.gemm_argmax_batch(self.lm_wp, s["final"], R, c.vocab_size, H, 1, 15, self.gws, self.block, 1,
+                                 dyn=self.dyn_t)
+        self._mark("lm_head", 0)
+        ops.norm_frag_batch(d["h"], R, m.w["norm"], eps, d["xn"], self.dyn_t, ops.DYN_BS)
+        ops.gemm_argmax_batch(self.lm_wp, s["xn"], R, c.vocab_size, H, 1, 15, self.gws, self.block, 1,
                               self.dyn_t, nrows_dyn_word=ops.DYN_BS)
+        self._mark("lm_head", 1)
 
     def verify(self) -> None:
         """Target verify of every live request's block (model/dflash.py:249-257, T = 0):
@@ -229,7 +233,8 @@ class BatchedDecoder:
         nsp = ops.batch_ksplit(H)
         ops.embed_rows_batch(t.embed, self.block, R, tt["h"], H, tt["ss_emb"], self.dyn_t, ops.DYN_BS)
         for i, lw in enumerate(t.layers):
-            ops.gemm_f32_batch(lw["qkv"], s["ln1"][i], R, t.nqkv, H, tt["part_qkv"], self.dyn_t)
+            ops.norm_frag_batch(tt["h"], R, lw["ln1"], t.eps, tt["xn"], self.dyn_t, ops.DYN_BS)
+            ops.gemm_f32_batch(lw["qkv"], s["xn"], R, t.nqkv, H, tt["part_qkv"], self.dyn_t)
             ops.attn_fused_batch(qkv=tt["part_qkv"], nsplit=nsp, split_stride=MT * 16 * t.nqkv, ld=t.nqkv, q_col=0,
                                  k_col=t.q_dim, v_col=t.q_dim + t.kv_dim, R=R, n_q=t.n_q, n_kv=t.n_kv,
                                  q_norm_w=lw["q_norm"], k_norm_w=lw["k_norm"], eps=t.eps, cos_tab=cos, sin_tab=sin,
@@ -237,12 +242,14 @@ class BatchedDecoder:
                                  dyn=self.dyn_t, kv_len_max=kvmax, ws=self.aws_t, max_splits=self.max_splits,
                                  out_frag=tt["attn"])
             ops.gemm_resid_batch(lw["o"], s["attn"], R, H, t.q_dim, tt["h"], add_residual=True, ws=self.gws,
-                                 dyn=self.dyn_t, ss_out=tt["ss_h"])
-            ops.gemm_silu_mul_batch(lw["gu"], s["ln2"][i], R, t.I, H, tt["act"], self.gws, self.dyn_t)
+                                 dyn=self.dyn_t)
+            ops.norm_frag_batch(tt["h"], R, lw["ln2"], t.eps, tt["xn"], self.dyn_t, ops.DYN_BS)
+            ops.gemm_silu_mul_batch(lw["gu"], s["xn"], R, t.I, H, tt["act"], self.gws, self.dyn_t)
             tap = taps[:, :, tl.index(i) * H:(tl.index(i) + 1) * H] if i in tl else None
             ops.gemm_resid_batch(lw["down"], s["act"], R, H, t.I, tt["h"], add_residual=True, ws=self.gws,
-                                 dyn=self.dyn_t, ss_out=tt["ss_h"], tap=tap)
-        ops.gemm_argmax_batch(self.lm_wp, s["final"], R, t.V, H, 0, 16, self.gws, self.post, 0, self.dyn_t,
+                                 dyn=self.dyn_t, tap=tap)
+        ops.norm_frag_batch(tt["h"], R, t.norm, t.eps, tt["xn"], self.dyn_t, ops.DYN_BS)
+        ops.gemm_argmax_batch(self.lm_wp, s["xn"], R, t.V, H, 0, 16, self.gws, self.post, 0, self.dyn_t,
                               nrows_dyn_word=ops.DYN_BS)
 
     def accept(self) -> list:
@@ -264,13 +271,17 @@ class BatchedDecoder:
     def cycle(self, draft_token_hook: Optional[Callable] = None) -> list:
         """One decode cycle of every live request.  draft_token_hook(r, block_row, start,
         call): test/bench instrumentation for scripted acceptance, as in DecodeSession."""
+        self._mark("draft", 0)
         self.draft()
+        self._mark("draft", 1)
         if draft_token_hook is not None:
             for r in range(self.R):
                 if self.live[r]:
                     draft_token_hook(r, self.block[r:r + 1], self.start[r], self.hook_calls[r])
                     self.hook_calls[r] += 1
+        self._mark("target", 0)
         self.verify()
+        self._mark("target", 1)
         return self.accept()
 
 

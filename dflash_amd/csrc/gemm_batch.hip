@@ -6,7 +6,7 @@
 // workgroup splitting K, the 16 partial tiles meeting in LDS — with one difference that
 // the register file forces: the activations of MT tiles over K = 4096 are MT x 128 KB,
 // i.e. the whole 512 KB VGPR file of a CU at MT = 4.  A workgroup therefore keeps only a
-// 2048-wide K slice of every tile resident (4 k-steps per wave, 64 VGPRs at MT = 4) and
+// 2048-wide K slice of every tile resident (8 waves x 8 k-steps, 128 VGPRs at MT = 4) and
 // K is cut over grid.y.  The fused epilogues need finished sums, so the K parts of a
 // tile column meet through HBM-resident fp32 partials (9 % of the weight bytes at
 // MT = 4) and the LAST workgroup of a column group to arrive — an agent-scope ticket, no
@@ -22,7 +22,8 @@ struct GemmBArgs {
   int64_t frag_stride, rows_stride, ss_stride;  // in elements of the respective buffers
   const int32_t *dyn;  // [R][DFL_DYN_WORDS]
   int KS, ntiles, nfr;
-  float *part;   // [ksplit][ntiles][MT][256] fp32 partial tiles (fused epilogues, ksplit > 1)
+  float *part;   // [ksplit][ntiles][MT][256] fp32 slabs, D layout (fused epilogues, ksplit > 1)
+  int64_t part_bytes;
   int *tickets;  // [gridDim.x], zero between launches
   // EPI_F32
   float *out;  // [ksplit][MT*16][ldo]
@@ -47,17 +48,36 @@ struct GemmBArgs {
   int64_t ss_out_stride;
 };
 
+// NW waves split the workgroup's K part; each keeps FR k-steps of every request's tile in
+// registers.  8 waves x 8 k-steps (not 16 x 4): a 512-thread workgroup alone on a CU gives
+// each wave 256 VGPRs — 128 for the activations of 4 tiles, 96 for THREE rotating weight
+// buffers, so two items (128 KB per CU) are in flight while one is in the MFMA.
+//
+// Finishing a tile: wave mt < MT sums the NW partial tiles of request mt in the MFMA D
+// layout (lane L holds floats 4L..4L+3 = row m = L & 15, columns 4 (L >> 4) .. +3):
+// conflict-free ds_read_b128, and every global access of the epilogue is 8 or 16 bytes wide.
+// The other waves run ahead into the next item.
+//
+// K parts (grid.y > 1, fused epilogues): each part's finished 16x16 sums go to HBM-resident
+// slabs with WRITE-THROUGH (sc1) 16-byte stores — no release fence, which would write back
+// the whole XCD L2 (MI355X_MICROARCH.md § visibility: 1.7-6.5 us per workgroup; the first
+// version of this kernel, with plain 4-byte slab stores + release, ran the ticketed GEMMs at
+// 1.0-2.6 TB/s) — then drain, barrier, one relaxed agent-scope ticket.  The last part to
+// arrive acquires (L1 invalidate only) and ALL its waves combine the slabs, 8 (tile, request)
+// items per wave in flight, in a fixed part order.
 template <int MT, int EPI>
-__global__ __launch_bounds__(1024) void k_gemm_b(GemmBArgs a) {
-  constexpr int FR = 4;
-  __shared__ float red[2][16][MT][256];
-  __shared__ float ssred[MT][16][16];
+__global__ __launch_bounds__(512) void k_gemm_b(GemmBArgs a) {
+  constexpr int FR = 8, NW = 8;
+  constexpr int TPU = EPI == EPI_SILU ? 2 : 1;  // tiles per epilogue unit (SILU: gate + up)
+  __shared__ float red[2][NW][MT][256];
+  __shared__ float ssred[MT][NW][16];
   __shared__ int s_last;
 
   const int tid = threadIdx.x;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l = tid & 63;
   const int ky = blockIdx.y, nky = gridDim.y;
+  const int fm = l & 15, fg = l >> 4;  // finishing lane: row, column group
 
   RowSrc src[MT];
   int nv[MT];
@@ -70,7 +90,7 @@ __global__ __launch_bounds__(1024) void k_gemm_b(GemmBArgs a) {
     nv[mt] = (a.src.valid_word >= 0 && a.dyn) ? a.dyn[mt * DFL_DYN_WORDS + a.src.valid_word] : 16;
   }
 
-  const int ks0 = (ky * 16 + w) * a.nfr;
+  const int ks0 = (ky * NW + w) * a.nfr;
   int nf0 = a.KS - ks0;
   nf0 = nf0 < 0 ? 0 : (nf0 > a.nfr ? a.nfr : nf0);
 
@@ -94,11 +114,12 @@ __global__ __launch_bounds__(1024) void k_gemm_b(GemmBArgs a) {
       if (f < nf0) wr[f] = ld_stream(base + (size_t)f * 64);
   };
 
-  bf16x8 wA[FR], wB[FR];
+  bf16x8 wA[FR], wB[FR], wC[FR];
   if (nseq > 0) load_item(wA, tile_of(0));  // the first weights leave for HBM before the prologue
+  if (nseq > 1) load_item(wB, tile_of(1));
 
   // ---- (mode 2) rstd of every request's rows: the nss partial sums of squares of a row are
-  // summed by the 16 waves together, then exchanged through LDS in a fixed order
+  // summed by the waves together, then exchanged through LDS in a fixed order
   float rstd[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) rstd[mt] = 1.f;
@@ -107,11 +128,11 @@ __global__ __launch_bounds__(1024) void k_gemm_b(GemmBArgs a) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       float t = 0.f;
-      for (int base = 0; base < a.src.nss; base += 256) {
+      for (int base = 0; base < a.src.nss; base += NW * 16) {
         float v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const int i = base + w + 16 * (part + 4 * u);
+          const int i = base + w + NW * (part + 4 * u);
           v[u] = src[mt].ss[(i < a.src.nss ? i : a.src.nss - 1) * 16 + m];
           v[u] = i < a.src.nss ? v[u] : 0.f;
         }
@@ -126,7 +147,7 @@ __global__ __launch_bounds__(1024) void k_gemm_b(GemmBArgs a) {
     for (int mt = 0; mt < MT; ++mt) {
       float t = 0.f;
 #pragma unroll
-      for (int ww = 0; ww < 16; ++ww) t += ssred[mt][ww][l & 15];
+      for (int ww = 0; ww < NW; ++ww) t += ssred[mt][ww][l & 15];
       rstd[mt] = rsqrtf(t / (float)(a.KS * 32) + a.src.eps);
     }
   }
@@ -145,50 +166,72 @@ __global__ __launch_bounds__(1024) void k_gemm_b(GemmBArgs a) {
     for (int mt = 0; mt < MT; ++mt) build_x<FR>(src[mt], ks, take, l, nv[mt], rstd[mt], xr[mt]);
   }
 
-  // finishing thread: request mt = tid >> 8, row m, column nl of the tile
-  const int fmt = tid >> 8, ff = tid & 255;
-  const int fm = ff >> 4, fnl = ff & 15;
-  float best = -INFINITY;
-  int bestn = 0x7fffffff;
-  float gate_sum = 0.f;
-  int arg_rows = 0;
-  if (EPI == EPI_ARGMAX && fmt < MT) {
-    arg_rows = a.nrows;
-    if (a.dyn && a.nrows_word >= 0) arg_rows = a.dyn[fmt * DFL_DYN_WORDS + a.nrows_word] - a.row0;
+  // ---- epilogue state of this lane, per request
+  float best[MT];
+  int bestn[MT], arg_rows[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    best[mt] = -INFINITY;
+    bestn[mt] = 0x7fffffff;
+    arg_rows[mt] = 0;
+    if (EPI == EPI_ARGMAX) {
+      arg_rows[mt] = a.nrows;
+      if (a.dyn && a.nrows_word >= 0) arg_rows[mt] = a.dyn[mt * DFL_DYN_WORDS + a.nrows_word] - a.row0;
+    }
   }
+  f32x4 gate_sum = {0.f, 0.f, 0.f, 0.f};
 
-  // the fused epilogues, on a finished sum s of (request fmt, row fm, column t*16 + fnl);
-  // `pos` = position of the tile in this workgroup's sequence
-  auto epilogue = [&](int t, int pos, float s) {
-    if (EPI == EPI_SILU) {
-      if ((pos & 1) == 0) {
-        gate_sum = s;
-      } else {  // tf:modeling_qwen3.py:82, rounded where torch rounds
-        const float gb = rbf(gate_sum), ub = rbf(s);
+  // The fused epilogues on the finished sums s[r] of (request mt, row fm, columns
+  // t*16 + 4 fg + r).  SILU: called with the gate tile's sums in g4 and the up tile's in s.
+  auto epilogue = [&](int t, int mt, const f32x4 &s, const f32x4 &g4) {
+    const int n0 = (EPI == EPI_SILU ? (t >> 1) : t) * 16 + 4 * fg;
+    if (EPI == EPI_SILU) {  // tf:modeling_qwen3.py:82, rounded where torch rounds
+      bf16x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float gb = rbf(g4[r]), ub = rbf(s[r]);
         const float act = rbf(gb / (1.f + __expf(-gb)));
-        const int n = (t >> 1) * 16 + fnl;
-        a.act[fmt * a.act_stride + ((size_t)(n >> 3) * 16 + fm) * 8 + (n & 7)] = f2bf(act * ub);
+        o[r] = f2bf(act * ub);
       }
+      *reinterpret_cast<bf16x4 *>(a.act + mt * a.act_stride + ((size_t)(n0 >> 3) * 16 + fm) * 8 + (n0 & 7)) = o;
     } else if (EPI == EPI_ARGMAX) {
-      const int n = t * 16 + fnl;
-      const float vb = rbf(s);
-      const bool live = (fm >= a.row0) && (fm < a.row0 + arg_rows);
-      if (a.logits && live) a.logits[fmt * a.logits_stride + (size_t)fm * a.N + n] = f2bf(s);
-      if (live && (vb > best || bestn == 0x7fffffff)) {  // n ascends along the sequence: first maximum kept
-        best = vb;
-        bestn = n;
+      const bool live = (fm >= a.row0) && (fm < a.row0 + arg_rows[mt]);
+      if (a.logits && live) {
+        bf16x4 o = {f2bf(s[0]), f2bf(s[1]), f2bf(s[2]), f2bf(s[3])};
+        *reinterpret_cast<bf16x4 *>(a.logits + mt * a.logits_stride + (size_t)fm * a.N + n0) = o;
       }
-    } else if (EPI == EPI_RESID) {
-      const int n = t * 16 + fnl;
-      const float v = rbf(s);
-      bf16_t *hp = a.h_io + fmt * a.h_stride + (int64_t)fm * a.ldh + n;
-      const float hn = a.add_resid ? rbf(bf2f(*hp) + v) : v;
-      *hp = f2bf(hn);
-      if (a.tap) a.tap[fmt * a.tap_stride + (int64_t)fm * a.ldtap + n] = f2bf(hn);
-      const float q = row_sum16(hn * hn);
-      if (fnl == 0 && a.ss_out) a.ss_out[fmt * a.ss_out_stride + t * 16 + fm] = q;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float vb = rbf(s[r]);  // n ascends with r, with the tile and with the wave's items: first maximum kept
+        if (live && (vb > best[mt] || bestn[mt] == 0x7fffffff)) {
+          best[mt] = vb;
+          bestn[mt] = n0 + r;
+        }
+      }
+    } else if (EPI == EPI_RESID) {  // model/dflash.py:140,144 residual adds (bf16 + bf16 -> bf16)
+      bf16_t *hp = a.h_io + mt * a.h_stride + (int64_t)fm * a.ldh + n0;
+      const bf16x4 hv = *reinterpret_cast<const bf16x4 *>(hp);
+      bf16x4 o;
+      float q = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = rbf(s[r]);
+        const float hn = a.add_resid ? rbf(bf2f(hv[r]) + v) : v;
+        o[r] = f2bf(hn);
+        q += hn * hn;
+      }
+      *reinterpret_cast<bf16x4 *>(hp) = o;
+      if (a.tap) *reinterpret_cast<bf16x4 *>(a.tap + mt * a.tap_stride + (int64_t)fm * a.ldtap + n0) = o;
+      q += __shfl_xor(q, 16, 64);
+      q += __shfl_xor(q, 32, 64);
+      if (fg == 0 && a.ss_out) a.ss_out[mt * a.ss_out_stride + t * 16 + fm] = q;
     }
   };
+
+  // slab of (K part ky, tile t, request mt): 256 floats in D layout, lane l owns 4l..4l+3
+  const __amdgpu_buffer_rsrc_t part_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(a.part, 0, a.part ? (int)a.part_bytes : 0, 0x00020000);
+  auto slab_off = [&](int k, int t, int mt) -> int { return ((((k * a.ntiles + t) * MT + mt) * 256) + 4 * l) * 4; };
 
   f32x4 acc[MT];
   auto process = [&](bf16x8(&wr)[FR], int t, int pos) {
@@ -205,79 +248,107 @@ __global__ __launch_bounds__(1024) void k_gemm_b(GemmBArgs a) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f32x4 *>(&red[buf][w][mt][l * 4]) = acc[mt];
     __syncthreads();
-    if (tid < MT * 256) {
-      const int idx = 4 * (fm + 16 * (fnl >> 2)) + (fnl & 3);  // D layout, see gemm_skinny.hip
-      float s = 0.f;
+    if (w < MT) {  // wave mt finishes request mt's tile
+      f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ww = 0; ww < 16; ++ww) s += red[buf][ww][fmt][idx];
-      if (EPI == EPI_F32)
-        a.out[((size_t)(ky * MT + fmt) * 16 + fm) * a.ldo + t * 16 + fnl] = s;
-      else if (nky == 1)
-        epilogue(t, pos, s);
-      else
-        a.part[(((size_t)ky * a.ntiles + t) * MT + fmt) * 256 + ff] = s;
+      for (int ww = 0; ww < NW; ++ww) s += *reinterpret_cast<const f32x4 *>(&red[buf][ww][w][l * 4]);
+      if (EPI == EPI_F32) {
+        *reinterpret_cast<f32x4 *>(a.out + ((size_t)(ky * MT + w) * 16 + fm) * a.ldo + t * 16 + 4 * fg) = s;
+      } else if (nky > 1) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, s), part_rsrc, slab_off(ky, t, w), 0, 16);  // sc1
+      } else if (EPI == EPI_SILU) {
+        if ((pos & 1) == 0)
+          gate_sum = s;
+        else
+          epilogue(t, w, s, gate_sum);
+      } else {
+        epilogue(t, w, s, s);
+      }
     }
   };
 
-  for (int j = 0; j < nseq; j += 2) {
-    if (j + 1 < nseq) load_item(wB, tile_of(j + 1));
+  // three rotating weight buffers: while one item is in the MFMA, the next two are in flight
+  for (int j = 0; j < nseq; j += 3) {
+    if (j + 2 < nseq) load_item(wC, tile_of(j + 2));
     process(wA, tile_of(j), j);
     if (j + 1 >= nseq) break;
-    if (j + 2 < nseq) load_item(wA, tile_of(j + 2));
+    if (j + 3 < nseq) load_item(wA, tile_of(j + 3));
     process(wB, tile_of(j + 1), j + 1);
+    if (j + 2 >= nseq) break;
+    if (j + 4 < nseq) load_item(wB, tile_of(j + 4));
+    process(wC, tile_of(j + 2), j + 2);
   }
 
   if (EPI != EPI_F32 && nky > 1) {
-    // ---- the K parts of this column group meet: last arriver finishes
+    // ---- the K parts of this column group meet: sc1 slabs are drained by every storing wave,
+    // then ONE relaxed agent-scope ticket; the last part to arrive combines
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const int ticket = __hip_atomic_fetch_add(&a.tickets[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int last = ticket == nky - 1;
       if (last) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(&a.tickets[blockIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // this CU's L1 may hold stale slab lines
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(&a.tickets[blockIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       s_last = last;
     }
     __syncthreads();
     if (!s_last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    if (tid < MT * 256) {
-      constexpr int U = 4;  // tiles whose partial loads are in flight together
-      for (int j0 = 0; j0 < nseq; j0 += U) {
-        float sv[U];
+    // items = (unit, request), dealt round-robin to the 8 waves; UB of a wave's items in flight
+    constexpr int UB = 8;
+    const int nitems = (nseq / TPU) * MT;
+    const float *pbase = a.part + 4 * l;
+    const size_t kstride = (size_t)a.ntiles * MT * 256;
+    for (int it0 = w; it0 < nitems; it0 += NW * UB) {
+      f32x4 sv[UB][TPU];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          sv[u] = 0.f;
-          const int j = j0 + u < nseq ? j0 + u : nseq - 1;
-          const float *pp = a.part + ((size_t)tile_of(j) * MT + fmt) * 256 + ff;
-          for (int k = 0; k < nky; ++k) sv[u] += __builtin_nontemporal_load(pp + (size_t)k * a.ntiles * MT * 256);
+      for (int b = 0; b < UB; ++b)
+#pragma unroll
+        for (int tp = 0; tp < TPU; ++tp) sv[b][tp] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int k = 0; k < nky; ++k) {
+#pragma unroll
+        for (int b = 0; b < UB; ++b) {
+          int it = it0 + b * NW;
+          it = it < nitems ? it : nitems - 1;
+          const int u = it / MT, mt = it - u * MT;
+#pragma unroll
+          for (int tp = 0; tp < TPU; ++tp)
+            sv[b][tp] += *reinterpret_cast<const f32x4 *>(pbase + k * kstride +
+                                                          ((size_t)tile_of(u * TPU + tp) * MT + mt) * 256);
         }
+      }
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-          if (j0 + u < nseq) epilogue(tile_of(j0 + u), j0 + u, sv[u]);
+      for (int b = 0; b < UB; ++b) {
+        const int it = it0 + b * NW;
+        if (it < nitems) {
+          const int u = it / MT, mt = it - u * MT;
+          epilogue(tile_of(u * TPU + TPU - 1), mt, sv[b][TPU - 1], sv[b][0]);
+        }
       }
     }
   }
 
   if (EPI == EPI_ARGMAX) {
-    if (tid < MT * 256) {
+    // every wave leaves its candidates: in the main loop wave mt saw request mt only, in the
+    // combine any wave may have seen any request
 #pragma unroll
-      for (int o = 1; o <= 8; o <<= 1) {
-        const float ov = __shfl_xor(best, o, 64);
-        const int oi = __shfl_xor(bestn, o, 64);
-        if (ov > best || (ov == best && oi < bestn)) {
-          best = ov;
-          bestn = oi;
+    for (int mt = 0; mt < MT; ++mt) {
+      float bv = best[mt];
+      int bn = bestn[mt];
+#pragma unroll
+      for (int o = 16; o <= 32; o <<= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const int oi = __shfl_xor(bn, o, 64);
+        if (ov > bv || (ov == bv && oi < bn)) {
+          bv = ov;
+          bn = oi;
         }
       }
-      if (fnl == 0) {
-        a.best_val[((size_t)blockIdx.x * MT + fmt) * 16 + fm] = best;
-        a.best_idx[((size_t)blockIdx.x * MT + fmt) * 16 + fm] = bestn;
+      if (fg == 0) {
+        a.best_val[(((size_t)blockIdx.x * NW + w) * MT + mt) * 16 + fm] = bv;
+        a.best_idx[(((size_t)blockIdx.x * NW + w) * MT + mt) * 16 + fm] = bn;
       }
     }
   }
@@ -338,11 +409,51 @@ __global__ __launch_bounds__(256) void k_embed_rows_b(const bf16_t *embed, const
   if (tid == 0) ss_out[r * ss_stride + m] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
+// frag[r] <- norm_w * bf16(h[r][m] * rsqrt(mean(h^2) + eps)) as frag16 (Qwen3RMSNorm,
+// tf:models/qwen3/modeling_qwen3.py:59-64), rows >= dyn valid count zeroed.  grid (16, R).
+// Batched GEMMs take normalised rows from here rather than normalising in their prologue:
+// that prologue runs in every workgroup (128x redundant) and at 4 request tiles costs ~10 us
+// of VALU per launch (scripts/bench_gemm_batch.py: qkv 25.6 us normed source vs 15.2 us frag).
+__global__ __launch_bounds__(256) void k_norm_frag_b(const bf16_t *h, int64_t h_stride, int64_t ldh,
+                                                     const bf16_t *nw, float eps, bf16x8 *frag,
+                                                     int64_t frag_stride8, int H, const int32_t *dyn, int dyn_word) {
+  __shared__ float wsum[4];
+  const int m = blockIdx.x, r = blockIdx.y, tid = threadIdx.x;
+  const int nv = dyn ? dyn[r * DFL_DYN_WORDS + dyn_word] : 16;
+  const int nchunks = H >> 3;
+  bf16x8 *out = frag + r * frag_stride8;
+  if (m >= nv) {
+    const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int c = tid; c < nchunks; c += 256) out[c * 16 + m] = z;
+    return;
+  }
+  const bf16_t *row = h + r * h_stride + (int64_t)m * ldh;
+  float ss = 0.f;
+  for (int c = tid; c < nchunks; c += 256) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8 *>(row + c * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ss += bf2f(v[j]) * bf2f(v[j]);
+  }
+  ss = wave_sum(ss);
+  if ((tid & 63) == 0) wsum[tid >> 6] = ss;
+  __syncthreads();
+  const float rstd = rsqrtf((wsum[0] + wsum[1] + wsum[2] + wsum[3]) / (float)H + eps);
+  for (int c = tid; c < nchunks; c += 256) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8 *>(row + c * 8);  // L1 hit
+    const bf16x8 wv = *reinterpret_cast<const bf16x8 *>(nw + c * 8);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(wv[j]) * rbf(bf2f(v[j]) * rstd));
+    out[c * 16 + m] = o;
+  }
+}
+
 constexpr int64_t WS_TICKETS = 1024;                                  // 256 ints
-constexpr int64_t WS_ARGMAX = 256 * 4 * 16 * (int64_t)(sizeof(float) + sizeof(int));  // best_val + best_idx
+constexpr int64_t WS_ARGMAX = 256 * 8 * 4 * 16 * (int64_t)(sizeof(float) + sizeof(int));  // [wg][wave][req][row]
 constexpr int64_t WS_HEAD = WS_TICKETS + WS_ARGMAX;
 
 int batch_ksplit(int K) { return (K / 32 + 63) / 64; }
+int mt_of(int R) { return R <= 2 ? 2 : 4; }
 
 bool fill_batch(GemmBArgs &a, const void *wp, const dfl_rows_batch *x, int R, int N, int K, const int32_t *dyn,
                 void *ws, const char *who) {
@@ -371,12 +482,13 @@ bool fill_batch(GemmBArgs &a, const void *wp, const dfl_rows_batch *x, int R, in
   a.KS = K / 32;
   a.ntiles = N / 16;
   const int ksplit = batch_ksplit(K);
-  a.nfr = (a.KS + 16 * ksplit - 1) / (16 * ksplit);
+  a.nfr = (a.KS + 8 * ksplit - 1) / (8 * ksplit);  // k-steps per wave: 8 waves split a K part
   if (ws) {
     a.tickets = (int *)ws;
     a.best_val = (float *)((char *)ws + WS_TICKETS);
-    a.best_idx = (int *)((char *)ws + WS_TICKETS + 256 * 4 * 16 * sizeof(float));
+    a.best_idx = (int *)((char *)ws + WS_TICKETS + 256 * 8 * 4 * 16 * sizeof(float));
     a.part = (float *)((char *)ws + WS_HEAD);
+    a.part_bytes = (int64_t)ksplit * a.ntiles * mt_of(R) * 256 * sizeof(float);
   }
   return true;
 }
@@ -385,11 +497,10 @@ template <int EPI>
 void launch_b(int R, dim3 grid, hipStream_t st, const GemmBArgs &a) {
   // MT is the compiled tile count: R = 3 runs as 4 with an empty fourth request, R = 1 as 2
   if (R <= 2)
-    hipLaunchKernelGGL((k_gemm_b<2, EPI>), grid, dim3(1024), 0, st, a);
+    hipLaunchKernelGGL((k_gemm_b<2, EPI>), grid, dim3(512), 0, st, a);
   else
-    hipLaunchKernelGGL((k_gemm_b<4, EPI>), grid, dim3(1024), 0, st, a);
+    hipLaunchKernelGGL((k_gemm_b<4, EPI>), grid, dim3(512), 0, st, a);
 }
-int mt_of(int R) { return R <= 2 ? 2 : 4; }
 
 }  // namespace
 
@@ -469,8 +580,8 @@ extern "C" int dfl_gemm_argmax_batch(const void *wp, const dfl_rows_batch *x, in
   const int ksplit = batch_ksplit(K);
   const int gx = grid_x_for(a.ntiles, ksplit);
   launch_b<EPI_ARGMAX>(R, dim3(gx, ksplit), (hipStream_t)stream, a);
-  // only the finishing workgroup of a column group writes best_*: every x index has exactly one
-  hipLaunchKernelGGL(k_argmax_finish_b, dim3(16, R), dim3(64), 0, (hipStream_t)stream, a.best_val, a.best_idx, gx,
+  // candidates per (column group, wave): only the finishing workgroup of a group writes them
+  hipLaunchKernelGGL(k_argmax_finish_b, dim3(16, R), dim3(64), 0, (hipStream_t)stream, a.best_val, a.best_idx, gx * 8,
                      mt_of(R), row0, nrows, dyn, nrows_dyn_word, out_ids, out_stride, out_off);
   DFL_CHECK_LAUNCH("dfl_gemm_argmax_batch");
   return DFL_OK;
@@ -484,5 +595,18 @@ extern "C" int dfl_embed_rows_batch(const void *embed, const int64_t *ids, int64
   hipLaunchKernelGGL(k_embed_rows_b, dim3(16, R), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)embed, ids,
                      ids_stride, (bf16_t *)h_out, h_stride, H, ss_out, ss_stride, dyn, dyn_word);
   DFL_CHECK_LAUNCH("dfl_embed_rows_batch");
+  return DFL_OK;
+}
+
+extern "C" int dfl_norm_frag_batch(const void *h, int64_t h_stride, int64_t ldh, int R, const void *norm_w, float eps,
+                                   void *frag, int64_t frag_stride, int H, const int32_t *dyn, int dyn_word,
+                                   void *stream) {
+  DFL_REQUIRE(h && norm_w && frag, "dfl_norm_frag_batch: null pointer");
+  DFL_REQUIRE(H > 0 && H % 8 == 0 && ldh >= H && ldh % 8 == 0 && frag_stride % 8 == 0 && frag_stride >= 16 * (int64_t)H,
+              "dfl_norm_frag_batch: bad shape / strides");
+  DFL_REQUIRE(R >= 1 && R <= 4, "dfl_norm_frag_batch: R outside 1..4");
+  hipLaunchKernelGGL(k_norm_frag_b, dim3(16, R), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)h, h_stride, ldh,
+                     (const bf16_t *)norm_w, eps, (bf16x8 *)frag, frag_stride / 8, H, dyn, dyn_word);
+  DFL_CHECK_LAUNCH("dfl_norm_frag_batch");
   return DFL_OK;
 }

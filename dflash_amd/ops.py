@@ -353,6 +353,15 @@ def embed_rows_batch(embed, ids: torch.Tensor, R: int, h_out: torch.Tensor, H: i
                                      dyn_word, _stream()), "dfl_embed_rows_batch")
 
 
+def norm_frag_batch(h: torch.Tensor, R: int, norm_w: torch.Tensor, eps: float, frag: torch.Tensor, dyn,
+                    dyn_word: int) -> None:
+    """h [MT, 16, H] -> frag [MT, 16*H] = frag16 of the RMS-normalised rows."""
+    assert h.dim() == 3 and h.stride(2) == 1 and frag.dim() == 2 and frag.is_contiguous()
+    check(lib().dfl_norm_frag_batch(_p(h[0, 0], BF16, "h"), h.stride(0), h.stride(1), R, _p(norm_w, BF16, "norm_w"), eps,
+                                    _p(frag, BF16, "frag"), frag.stride(0), h.shape[2], _p(dyn, I32, "dyn"), dyn_word,
+                                    _stream()), "dfl_norm_frag_batch")
+
+
 def kv_append_batch(*, kv, nsplit, split_stride, ld, k_col, v_col, col_layer_stride, n_layers, R, n_kv, k_norm_w,
                     eps, cos_tab, sin_tab, kcache, vcache, dyn) -> None:
     """kcache/vcache [MT, L, n_kv, rows, 128]; k_norm_w [L, 128] or None."""

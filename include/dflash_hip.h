@@ -257,6 +257,14 @@ int dfl_embed_rows_batch(const void *embed, const int64_t *ids, int64_t ids_stri
                          int64_t h_stride, int H, float *ss_out, int64_t ss_stride, const int32_t *dyn, int dyn_word,
                          void *stream);
 
+/* RMSNorm of R requests' residual rows straight into frag16 (Qwen3RMSNorm,
+ * tf:models/qwen3/modeling_qwen3.py:59-64): frag[r] = norm_w * bf16(h[r] * rstd), rows >=
+ * dyn[r][dyn_word] zeroed.  The batched GEMMs read their normalised operand from here (the
+ * in-GEMM norm of the single-request path is replicated in every workgroup, which at 4 tiles
+ * costs more than this launch). */
+int dfl_norm_frag_batch(const void *h, int64_t h_stride, int64_t ldh, int R, const void *norm_w, float eps, void *frag,
+                        int64_t frag_stride, int H, const int32_t *dyn, int dyn_word, void *stream);
+
 /* Context K/V of ALL draft layers for R requests in one launch (model/dflash.py:73-85, the
  * context half): kv = fp32 partials of the context rows times the concatenated k/v weights
  * of the n_layers layers (layer i's k columns at k_col + i * col_layer_stride, v alike);

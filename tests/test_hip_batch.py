@@ -136,3 +136,145 @@ def test_batched_draft_and_verify_match_single_kernels():
                 a, b = dec.tk[r, li][:, :s.start], s.tcache.k[li][:, :s.start]
                 dd = (a.float() - b.float()).abs()
                 assert dd.max() <= 6e-2 * b.float().abs().max() and dd.mean() <= 4e-3 * b.float().abs().max()
+
+
+# ------------------------------------------------------------------ kernel level
+def _gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def _unfrag(frag, K):
+    return frag.view(K // 8, 16, 8).permute(1, 0, 2).reshape(16, K)
+
+
+def _frag_of(x):  # x [MT, 16, K] bf16 cuda -> [MT, 16*K] frag16
+    from dflash_amd import ops
+    MT, _, K = x.shape
+    out = torch.empty(MT, 16 * K, dtype=BF16, device=x.device)
+    for r in range(MT):
+        ops.pack_rows(x[r], 16, out[r])
+    return out
+
+
+def _dyn(vals, MT):
+    d = torch.zeros(MT, 8, dtype=torch.int32)
+    for r, (tau, bs) in enumerate(vals):
+        d[r, 1], d[r, 2] = tau, bs
+    return d.to(dev())
+
+
+@pytest.mark.parametrize("R,N,K", [(1, 64, 512), (2, 48, 4096), (3, 256, 4096), (4, 4096, 4096), (4, 512, 12288),
+                                   (4, 256, 20480), (3, 128, 9728), (4, 64, 2048 + 32)])
+def test_gemm_resid_batch_exact_small_ints(R, N, K):
+    """Small-integer operands: products and sums are exact in fp32 whatever the order, so
+    the batched GEMM (K parts through partial tiles, last-arriver finish, residual add,
+    taps, sums of squares, per-request valid rows) must match torch bit for bit."""
+    from dflash_amd import ops
+    MT = ops.batch_tiles(R)
+    g = _gen(R * 1000 + N + K)
+    w = torch.randint(-2, 3, (N, K), generator=g).to(BF16).to(dev())
+    x = torch.randint(-2, 3, (MT, 16, K), generator=g).to(BF16).to(dev())
+    h0 = torch.randint(-8, 9, (MT, 16, N), generator=g).to(BF16).to(dev())
+    rows = [(0, [16, 5, 1, 9][r] if r < R else 0) for r in range(MT)]
+    dyn = _dyn(rows, MT)
+    wp = ops.pack_weight(w)
+    ws = ops.gemm_batch_ws(N, K, dev())
+    for mode in ("frag", "rows"):
+        h = h0.clone()
+        tap = torch.zeros(MT, 16, N + 32, dtype=BF16, device=dev())
+        ss = torch.zeros(MT, N, dtype=torch.float32, device=dev())
+        src = ops.brows_frag(_frag_of(x)) if mode == "frag" else ops.brows_plain(x, ops.DYN_BS)
+        for _ in range(2):   # twice: the tickets must be back at zero after a launch
+            h.copy_(h0)
+            ops.gemm_resid_batch(wp, src, R, N, K, h, add_residual=True, ws=ws, dyn=dyn, ss_out=ss,
+                                 tap=tap[:, :, 16:16 + N])
+        for r in range(R):
+            nv = 16 if mode == "frag" else rows[r][1]
+            xe = x[r].float().clone()
+            xe[nv:] = 0
+            want = (h0[r].float() + (xe @ w.float().T).to(BF16).float()).to(BF16)
+            assert torch.equal(h[r], want), (mode, r)
+            assert torch.equal(tap[r, :, 16:16 + N], want)
+            sse = want.float().pow(2).view(16, N // 16, 16).sum(-1).T          # [tile][row]
+            assert torch.allclose(ss[r].view(N // 16, 16), sse, rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("R,I,K", [(2, 64, 512), (4, 1024, 4096), (3, 12288 // 8, 4096)])
+def test_gemm_silu_mul_batch(R, I, K):
+    from dflash_amd import ops
+    MT = ops.batch_tiles(R)
+    g = _gen(I + K + R)
+    gate = (torch.randn(I, K, generator=g) * 0.05).to(BF16).to(dev())
+    up = (torch.randn(I, K, generator=g) * 0.05).to(BF16).to(dev())
+    x = torch.randn(MT, 16, K, generator=g).to(BF16).to(dev())
+    dyn = _dyn([(0, 16)] * MT, MT)
+    act = torch.zeros(MT, 16 * I, dtype=BF16, device=dev())
+    act1 = torch.zeros(16 * I, dtype=BF16, device=dev())
+    wp = ops.pack_weight_gateup(gate, up)
+    ws = ops.gemm_batch_ws(2 * I, K, dev())
+    ops.gemm_silu_mul_batch(wp, ops.brows_plain(x, ops.DYN_BS), R, I, K, act, ws, dyn)
+    for r in range(R):
+        gb = (x[r].float() @ gate.float().T).to(BF16).float()
+        ub = (x[r].float() @ up.float().T).to(BF16).float()
+        want = (torch.nn.functional.silu(gb).to(BF16).float() * ub).to(BF16).float()
+        got = _unfrag(act[r], I).float()
+        d = (got - want).abs()
+        assert d.max() <= 2e-2 * want.abs().max() and d.mean() <= 2e-3 * want.abs().max()
+        # and against the single-request kernel (same rounding points, other summation order)
+        ops.gemm_silu_mul(wp, ops.rows_plain(x[r]), I, K, act1)
+        d1 = (got - _unfrag(act1, I).float()).abs()
+        assert d1.max() <= 2e-2 * want.abs().max()
+
+
+@pytest.mark.parametrize("R,V,K,row0", [(2, 2048, 512, 1), (4, 4096 + 16 * 7, 4096, 0), (3, 151936, 4096, 1)])
+def test_gemm_argmax_batch(R, V, K, row0):
+    """Fused lm_head + argmax for R requests with different row counts: ids equal
+    torch.argmax of the bf16 logits the same kernel materialises, and the logits equal
+    the fp32 reference within bf16 rounding."""
+    from dflash_amd import ops
+    MT = ops.batch_tiles(R)
+    g = _gen(V + K)
+    w = (torch.randn(V, K, generator=g) * 0.05).to(BF16).to(dev())
+    x = torch.randn(MT, 16, K, generator=g).to(BF16).to(dev())
+    bss = [16, 12, 3, 7][:R] + [0] * (MT - R)
+    dyn = _dyn([(0, b) for b in bss], MT)
+    wp = ops.pack_weight(w)
+    ws = ops.gemm_batch_ws(V, K, dev())
+    ids = torch.full((MT, 16), -1, dtype=torch.int64, device=dev())
+    logits = torch.zeros(MT, 16, V, dtype=BF16, device=dev())
+    ops.gemm_argmax_batch(wp, ops.brows_plain(x, ops.DYN_BS), R, V, K, row0, 16 - row0, ws, ids, row0, dyn,
+                          nrows_dyn_word=ops.DYN_BS, logits=logits)
+    for r in range(R):
+        n = bss[r] - row0
+        ref = (x[r].float() @ w.float().T)[row0:bss[r]]
+        lg = logits[r, row0:bss[r]]
+        assert (lg.float() - ref).abs().max() <= 2e-2 * ref.abs().max()
+        assert torch.equal(ids[r, row0:row0 + n], torch.argmax(lg, dim=-1))
+        assert torch.all(ids[r, row0 + n:] == -1) and torch.all(ids[r, :row0] == -1)
+
+
+def test_gemm_f32_batch_and_normed_source():
+    """fp32 partial output over the K parts + the RMSNorm row source (sum-of-squares
+    partials left by a producer): sum of the parts equals the reference GEMM of the
+    normalised rows."""
+    from dflash_amd import ops
+    R, N, K = 3, 6144, 4096
+    MT = ops.batch_tiles(R)
+    g = _gen(5)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(BF16).to(dev())
+    h = torch.randn(MT, 16, K, generator=g).to(BF16).to(dev())
+    nw = (1 + 0.1 * torch.randn(K, generator=g)).to(BF16).to(dev())
+    ss = h.float().pow(2).view(MT, 16, K // 16, 16).sum(-1).permute(0, 2, 1).contiguous().view(MT, K)  # [tile][row]
+    dyn = _dyn([(0, 16), (0, 9), (0, 2), (0, 0)], MT)
+    ks = ops.batch_ksplit(K)
+    out = torch.zeros(ks * MT * 16 * N, dtype=torch.float32, device=dev())
+    ops.gemm_f32_batch(ops.pack_weight(w), ops.brows_normed(h, ss, K // 16, nw, 1e-6, ops.DYN_BS), R, N, K, out, dyn)
+    got = out.view(ks, MT, 16, N).sum(0)
+    for r, nv in enumerate([16, 9, 2]):
+        hf = h[r].float()
+        xn = (nw.float() * (hf * torch.rsqrt(hf.pow(2).mean(-1, keepdim=True) + 1e-6)).to(BF16).float()).to(BF16).float()
+        want = xn @ w.float().T
+        want[nv:] = 0
+        d = (got[r] - want).abs()
+        assert d.max() <= 1e-2 * want.abs().max(), r
+        assert torch.count_nonzero(got[r, nv:]) == 0
