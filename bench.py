@@ -210,8 +210,12 @@ def batched_leg(args, rank, dev, draft, target, perm, cfg):
             blk[0, k + 1] = torch.where(blk[0, k + 1] == wrong, (wrong + 1) % 151000, blk[0, k + 1])
 
     dec.cycle(hook)
+    step = dec.cycle
+    if args.graph:
+        dec.capture()
+        step = dec.cycle_graph
     for _ in range(args.warmup):
-        dec.cycle(hook)
+        step(hook)
     ev_all = []
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
@@ -220,7 +224,7 @@ def batched_leg(args, rank, dev, draft, target, perm, cfg):
     tokens = 0
     for _ in range(args.steps):
         dec.events = {}
-        out = dec.cycle(hook)
+        out = step(hook)
         ev_all.append(dec.events)
         tokens += sum(o[0] for o in out)
     torch.cuda.synchronize()
@@ -343,6 +347,9 @@ def main():
     ap.add_argument("--requests-per-gpu", type=int, default=1,
                     help="R > 1: R requests per GPU decode as one ragged batch sharing the weight stream "
                          "(BASELINE.json configs[2] uses 4); needs the native verify")
+    ap.add_argument("--graph", action="store_true",
+                    help="with --requests-per-gpu > 1: replay the cycle as three captured hipGraphs instead of ~300 "
+                         "launches (same GPU time: the launches are not the bottleneck; frees the host core)")
     ap.add_argument("--hf-verify", action="store_true",
                     help="verify through the HF/PyTorch target forward (round-1 configuration) instead of "
                          "dflash_amd.NativeTarget")

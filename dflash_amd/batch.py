@@ -181,10 +181,15 @@ class BatchedDecoder:
     def draft(self) -> None:
         """Draft forward + lm_head + greedy unmask for every live request
         (model/dflash.py:237-247): block[r, 1:bs] <- argmax."""
+        self._draft_body(self._kv_len_max())
+        self._mark("lm_head", 0)
+        self._draft_head()
+        self._mark("lm_head", 1)
+
+    def _draft_body(self, kvmax: int) -> None:
         m, c, d, s, R, MT = self.model, self.cfg, self.d, self.src_d, self.R, self.MT
         H, I = c.hidden_size, c.intermediate_size
         L = m.w["layers"]
-        kvmax = self._kv_len_max()
         cos, sin = m._rope_tab(kvmax + 64)
         ops.embed_rows_batch(self.embed_w, self.block, R, d["h"], H, d["ss_emb"], self.dyn_t, ops.DYN_BS)
         # context rows: fc, then K/V of all layers appended to the draft caches
@@ -214,17 +219,18 @@ class BatchedDecoder:
             ops.gemm_silu_mul_batch(lw["gu"], s["xn"], R, I, H, d["act"], self.gws, self.dyn_t)
             ops.gemm_resid_batch(lw["down"], s["act"], R, H, I, d["h"], add_residual=True, ws=self.gws,
                                  dyn=self.dyn_t)
-        self._mark("lm_head", 0)
-        ops.norm_frag_batch(d["h"], R, m.w["norm"], eps, d["xn"], self.dyn_t, ops.DYN_BS)
-        ops.gemm_argmax_batch(self.lm_wp, s["xn"], R, c.vocab_size, H, 1, 15, self.gws, self.block, 1,
-                              self.dyn_t, nrows_dyn_word=ops.DYN_BS)
-        self._mark("lm_head", 1)
 
-    def verify(self) -> None:
+    def _draft_head(self) -> None:
+        m, c, d, s, R = self.model, self.cfg, self.d, self.src_d, self.R
+        ops.norm_frag_batch(d["h"], R, m.w["norm"], c.rms_norm_eps, d["xn"], self.dyn_t, ops.DYN_BS)
+        ops.gemm_argmax_batch(self.lm_wp, s["xn"], R, c.vocab_size, c.hidden_size, 1, 15, self.gws, self.block, 1,
+                              self.dyn_t, nrows_dyn_word=ops.DYN_BS)
+
+    def verify(self, kvmax: Optional[int] = None) -> None:
         """Target verify of every live request's block (model/dflash.py:249-257, T = 0):
         post[r] <- the target's greedy tokens, taps[r] <- the tapped layers' hidden rows."""
         t, tt, s, R, MT, H = self.target, self.t, self.src_t, self.R, self.MT, self.cfg.hidden_size
-        kvmax = self._kv_len_max()
+        kvmax = kvmax or self._kv_len_max()
         cos, sin = t._rope_tab(kvmax + 64)
         taps = self.d["taps"]
         tl = list(self.model.target_layer_ids)
@@ -252,11 +258,15 @@ class BatchedDecoder:
         ops.gemm_argmax_batch(self.lm_wp, s["xn"], R, t.V, H, 0, 16, self.gws, self.post, 0, self.dyn_t,
                               nrows_dyn_word=ops.DYN_BS)
 
-    def accept(self) -> list:
-        """Acceptance scan + commit + rollback bookkeeping of all requests (:258-268) and
-        the cycle's one device->host read.  Returns per request (tau, stop) or None."""
+    def _accept_launch(self) -> None:
         ops.accept_commit_batch(self.block, self.post, self.R, self.output_ids, self.dyn_d, self.dyn_t, self.stop_t,
                                 self.result, rearm_mask_id=self.mask_id)
+
+    def accept(self, launch: bool = True) -> list:
+        """Acceptance scan + commit + rollback bookkeeping of all requests (:258-268) and
+        the cycle's one device->host read.  Returns per request (tau, stop) or None."""
+        if launch:
+            self._accept_launch()
         res = self.result[:self.R].tolist()
         out = []
         for r in range(self.R):
@@ -266,6 +276,47 @@ class BatchedDecoder:
             self.start[r] = res[r][1]
             out.append((res[r][0] + 1, bool(res[r][2])))
         return out
+
+    # ------------------------------------------------------------------ hipGraph
+    @torch.inference_mode()
+    def capture(self) -> None:
+        """Capture the cycle's launch sequence (~300 kernels) into three hipGraphs: draft body,
+        lm_head + unmask, verify + accept.  Every length the kernels need is read from `dyn`
+        on the device, so one capture serves every cycle; the key-split count of the attention
+        launches is fixed at the cache capacity (splits past a request's keys are empty).
+        The host then spends three graph launches per cycle instead of ~300 ctypes calls."""
+        kv = self.max_rows
+        self.model._rope_tab(kv + 64)
+        self.target._rope_tab(kv + 64)
+        torch.cuda.synchronize(self.dev)
+        self.graphs = {}
+        for name, fn in (("body", lambda: self._draft_body(kv)), ("head", self._draft_head),
+                         ("verify", lambda: (self.verify(kv), self._accept_launch()))):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                fn()
+            self.graphs[name] = g
+
+    @torch.inference_mode()
+    def cycle_graph(self, draft_token_hook: Optional[Callable] = None) -> list:
+        """`cycle` through the captured graphs (call `capture()` once after the first eager
+        cycle).  Note the capture itself replays nothing: state only advances here."""
+        g = self.graphs
+        self._mark("draft", 0)
+        g["body"].replay()
+        self._mark("lm_head", 0)
+        g["head"].replay()
+        self._mark("lm_head", 1)
+        self._mark("draft", 1)
+        if draft_token_hook is not None:
+            for r in range(self.R):
+                if self.live[r]:
+                    draft_token_hook(r, self.block[r:r + 1], self.start[r], self.hook_calls[r])
+                    self.hook_calls[r] += 1
+        self._mark("target", 0)
+        g["verify"].replay()
+        self._mark("target", 1)
+        return self.accept(launch=False)
 
     @torch.inference_mode()
     def cycle(self, draft_token_hook: Optional[Callable] = None) -> list:

@@ -4,7 +4,7 @@ kernel names in those files run to kilobytes).  usage: kstats.py <dir-or-csv> [m
 import csv, glob, os, re, sys
 p = sys.argv[1]
 if os.path.isdir(p):
-    p = sorted(glob.glob(os.path.join(p, "**", "*kernel_stats.csv"), recursive=True))[-1]
+    p = max(glob.glob(os.path.join(p, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
 rows = list(csv.DictReader(open(p)))
 for r in rows:
     n = r["Name"]

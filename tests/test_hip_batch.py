@@ -278,3 +278,35 @@ def test_gemm_f32_batch_and_normed_source():
         d = (got[r] - want).abs()
         assert d.max() <= 1e-2 * want.abs().max(), r
         assert torch.count_nonzero(got[r, nv:]) == 0
+
+
+def test_graph_replay_matches_eager_cycles():
+    """The captured hipGraphs (draft body / lm_head / verify + accept) advance the requests
+    exactly like the kernel-by-kernel launches: same committed ids, same tau per cycle."""
+    from dflash_amd.batch import BatchedDecoder
+    from dflash_amd.synthetic import greedy_walk
+    cfg, m, hf, nt, perm = _setup()
+    lens = (33, 50, 21)
+    prompts = [torch.randint(0, 2000, (1, P), generator=torch.Generator().manual_seed(40 + i)).to(dev())
+               for i, P in enumerate(lens)]
+    Gs = [greedy_walk(perm, p, 300).to(dev()) for p in prompts]
+    plans = [H.make_plan(64, 16, 17 + i) for i in range(3)]
+    hooks = [_hook_for(Gs[i], plans[i]) for i in range(3)]
+    runs = []
+    for use_graph in (False, True):
+        dec = BatchedDecoder(m, nt, 3, max_rows=400, out_len=400, mask_token_id=cfg.mask_token_id)
+        for r, p in enumerate(prompts):
+            dec.admit(r, p)
+        taus = [dec.cycle(lambda r, b, s, c: hooks[r](b, s, c))]
+        if use_graph:
+            dec.capture()
+        for _ in range(12):
+            step = dec.cycle_graph if use_graph else dec.cycle
+            taus.append(step(lambda r, b, s, c: hooks[r](b, s, c)))
+        runs.append((taus, dec.output_ids.clone(), list(dec.start)))
+    assert runs[0][0] == runs[1][0]
+    assert runs[0][2] == runs[1][2]
+    assert torch.equal(runs[0][1], runs[1][1])
+    for r in range(3):
+        n = runs[1][2][r]
+        assert torch.equal(runs[1][1][r, :n + 1], Gs[r][:n + 1])
