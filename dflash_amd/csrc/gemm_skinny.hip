@@ -43,6 +43,7 @@ struct GemmArgs {
   int nrows_word;
   float *best_val;  // [gridDim.x][16]
   int *best_idx;
+  float *best2_val;  // [gridDim.x][16] runner-up value (top-2 logit margin), optional
   bf16_t *logits;  // optional [16][N]
   int N;
   // EPI_RESID
@@ -99,6 +100,7 @@ __global__ __launch_bounds__(1024) void k_gemm(GemmArgs a) {
   // finishing thread f < MT*256: row m = (f&255)>>4, column nl = f&15 of the tile
   float best = -INFINITY;  // running argmax
   int bestn = 0x7fffffff;
+  float second = -INFINITY;  // runner-up VALUE as torch.topk(2) defines it: a tie with the best counts
   float gate_sum = 0.f;    // SILU: the pair's gate sum, kept across one position
   int arg_rows = 0;
   if (EPI == EPI_ARGMAX) {
@@ -169,8 +171,11 @@ __global__ __launch_bounds__(1024) void k_gemm(GemmArgs a) {
         if (a.logits && live) a.logits[(size_t)m * a.N + n] = f2bf(s);
         // n grows along the sequence for a fixed thread: strict '>' keeps the first maximum
         if (live && (vb > best || bestn == 0x7fffffff)) {
+          second = best;
           best = vb;
           bestn = n;
+        } else if (live) {
+          second = fmaxf(second, vb);
         }
       } else {  // EPI_RESID: model/dflash.py:140,144 residual adds (bf16 + bf16 -> bf16)
         const int n = t * 16 + nl;
@@ -291,6 +296,8 @@ __global__ __launch_bounds__(1024) void k_gemm(GemmArgs a) {
       for (int o = 1; o <= 8; o <<= 1) {
         const float ov = __shfl_xor(best, o, 64);
         const int oi = __shfl_xor(bestn, o, 64);
+        const float os = __shfl_xor(second, o, 64);
+        second = fmaxf(fmaxf(second, os), fminf(best, ov));  // runner-up of the union
         if (ov > best || (ov == best && oi < bestn)) {
           best = ov;
           bestn = oi;
@@ -299,24 +306,29 @@ __global__ __launch_bounds__(1024) void k_gemm(GemmArgs a) {
       if ((tid & 15) == 0) {
         a.best_val[blockIdx.x * 16 + (tid >> 4)] = best;
         a.best_idx[blockIdx.x * 16 + (tid >> 4)] = bestn;
+        if (a.best2_val) a.best2_val[blockIdx.x * 16 + (tid >> 4)] = second;
       }
     }
   }
 }
 
-// Cross-workgroup finish of the fused argmax: one wave per row.
-__global__ __launch_bounds__(64) void k_argmax_finish(const float *best_val, const int *best_idx, int nblk, int row0,
-                                                      int nrows, const int32_t *dyn, int nrows_word,
-                                                      int64_t *out_ids, int out_off) {
+// Cross-workgroup finish of the fused argmax: one wave per row.  margin_out (optional):
+// top-1 minus top-2 logit of the row — the reference's only confidence statistic
+// (benchmark_candidate_solutions.py:296-302: topk(2) values, a tie gives 0).
+__global__ __launch_bounds__(64) void k_argmax_finish(const float *best_val, const int *best_idx, const float *best2_val,
+                                                      int nblk, int row0, int nrows, const int32_t *dyn, int nrows_word,
+                                                      int64_t *out_ids, int out_off, float *margin_out) {
   int rows = nrows;
   if (dyn && nrows_word >= 0) rows = dyn[nrows_word] - row0;
   const int m = row0 + blockIdx.x;
   if ((int)blockIdx.x >= rows) return;
-  float bv = -INFINITY;
+  float bv = -INFINITY, sv = -INFINITY;
   int bi = 0x7fffffff;
   for (int b = threadIdx.x; b < nblk; b += 64) {
     const float ov = best_val[b * 16 + m];
     const int oi = best_idx[b * 16 + m];
+    const float os = best2_val ? best2_val[b * 16 + m] : -INFINITY;
+    if (oi != 0x7fffffff) sv = fmaxf(fmaxf(sv, os), bi == 0x7fffffff ? -INFINITY : fminf(bv, ov));
     if (ov > bv || (ov == bv && oi < bi) || bi == 0x7fffffff) {
       bv = ov;
       bi = oi;
@@ -326,12 +338,19 @@ __global__ __launch_bounds__(64) void k_argmax_finish(const float *best_val, con
   for (int o = 32; o > 0; o >>= 1) {
     const float ov = __shfl_xor(bv, o, 64);
     const int oi = __shfl_xor(bi, o, 64);
-    if (ov > bv || (ov == bv && oi < bi)) {
+    const float os = __shfl_xor(sv, o, 64);
+    const bool have = bi != 0x7fffffff, ohave = oi != 0x7fffffff;
+    sv = fmaxf(sv, os);
+    if (have && ohave) sv = fmaxf(sv, fminf(bv, ov));
+    if (ohave && (!have || ov > bv || (ov == bv && oi < bi))) {
       bv = ov;
       bi = oi;
     }
   }
-  if (threadIdx.x == 0) out_ids[out_off + blockIdx.x] = (int64_t)bi;
+  if (threadIdx.x == 0) {
+    out_ids[out_off + blockIdx.x] = (int64_t)bi;
+    if (margin_out) margin_out[out_off + blockIdx.x] = bv - sv;
+  }
 }
 
 // ---- one-time packing ---------------------------------------------------------
@@ -454,11 +473,11 @@ extern "C" int dfl_gemm_silu_mul(const void *wp_gateup, const dfl_rows *x, int I
   return DFL_OK;
 }
 
-extern "C" int64_t dfl_argmax_ws_bytes(void) { return 256 * 16 * (int64_t)(sizeof(float) + sizeof(int)); }
+extern "C" int64_t dfl_argmax_ws_bytes(void) { return 256 * 16 * (int64_t)(2 * sizeof(float) + sizeof(int)); }
 
 extern "C" int dfl_gemm_argmax(const void *wp, const dfl_rows *x, int V, int K, int row0, int nrows,
                                const int32_t *dyn, int nrows_dyn_word, void *ws, int64_t *out_ids, int out_off,
-                               void *logits, void *stream) {
+                               void *logits, float *margin_out, void *stream) {
   DFL_REQUIRE(wp && ws && out_ids, "dfl_gemm_argmax: null pointer");
   DFL_REQUIRE(V > 0 && K > 0 && V % 16 == 0 && K % 32 == 0, "dfl_gemm_argmax: need V%%16==0, K%%32==0 (V=%d K=%d)", V, K);
   DFL_REQUIRE(row0 >= 0 && nrows >= 0 && row0 + nrows <= 16, "dfl_gemm_argmax: rows [%d,%d) outside the 16-row tile", row0,
@@ -478,12 +497,13 @@ extern "C" int dfl_gemm_argmax(const void *wp, const dfl_rows *x, int V, int K, 
   a.nrows_word = nrows_dyn_word;
   a.best_val = (float *)ws;
   a.best_idx = (int *)((char *)ws + 256 * 16 * sizeof(float));
+  a.best2_val = margin_out ? (float *)((char *)ws + 256 * 16 * (sizeof(float) + sizeof(int))) : nullptr;
   a.logits = (bf16_t *)logits;
   a.N = V;
   const int gx = grid_x_for(a.ntiles);
   hipLaunchKernelGGL((k_gemm<1, false, EPI_ARGMAX>), dim3(gx, 1), dim3(1024), 0, (hipStream_t)stream, a);
-  hipLaunchKernelGGL(k_argmax_finish, dim3(16), dim3(64), 0, (hipStream_t)stream, a.best_val, a.best_idx, gx, row0,
-                     nrows, dyn, nrows_dyn_word, out_ids, out_off);
+  hipLaunchKernelGGL(k_argmax_finish, dim3(16), dim3(64), 0, (hipStream_t)stream, a.best_val, a.best_idx, a.best2_val, gx,
+                     row0, nrows, dyn, nrows_dyn_word, out_ids, out_off, margin_out);
   DFL_CHECK_LAUNCH("dfl_gemm_argmax");
   return DFL_OK;
 }

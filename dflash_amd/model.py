@@ -291,11 +291,13 @@ class DFlashDraftModel:
         return src["final"]
 
     def draft_tokens(self, hid_frag: torch.Tensor, lm_head_wp: torch.Tensor, bs: int, block_ids: torch.Tensor,
-                     logits: Optional[torch.Tensor] = None) -> None:
-        """block_ids[1:bs] <- argmax(lm_head(hidden[1:bs])) (model/dflash.py:238,245,247)."""
+                     logits: Optional[torch.Tensor] = None, margins: Optional[torch.Tensor] = None) -> None:
+        """block_ids[1:bs] <- argmax(lm_head(hidden[1:bs])) (model/dflash.py:238,245,247).
+        margins (fp32 [>= bs]): margins[j] <- top-1 minus top-2 draft logit of block slot j >= 1,
+        the reference's per-position confidence (benchmark_candidate_solutions.py:296-302)."""
         c, ws = self.config, self._workspace()
         ops.gemm_argmax(lm_head_wp, hid_frag, c.vocab_size, c.hidden_size, 1, bs - 1, ws["argmax_ws"], block_ids, 1,
-                        logits=logits)
+                        logits=logits, margins=margins)
 
     # ------------------------------------------------------------------ reference API
     @torch.inference_mode()

@@ -118,10 +118,15 @@ int dfl_gemm_silu_mul(const void *wp_gateup, const dfl_rows *x, int I, int K, vo
  * model/utils.py:28-29).  The 15 x V logits are never materialised unless
  * `logits` != NULL (bf16 [16][V], rows outside the range untouched).
  * ws: workspace of dfl_argmax_ws_bytes() bytes.  out_ids int64, written at
- * out_ids[r - row0 + out_off]. nrows_dyn_word >= 0: rows = dyn[word] - row0. */
+ * out_ids[r - row0 + out_off]. nrows_dyn_word >= 0: rows = dyn[word] - row0.
+ * margin_out (optional, fp32, same indexing as out_ids): top-1 minus top-2 bf16 logit of the
+ * row, the reference's confidence statistic (benchmark_candidate_solutions.py:296-302,
+ * torch.topk(2) values: an exact tie gives 0) — the per-position confidence comes with the
+ * unmask at no extra pass over the logits. */
 int64_t dfl_argmax_ws_bytes(void);
 int dfl_gemm_argmax(const void *wp, const dfl_rows *x, int V, int K, int row0, int nrows, const int32_t *dyn,
-                    int nrows_dyn_word, void *ws, int64_t *out_ids, int out_off, void *logits, void *stream);
+                    int nrows_dyn_word, void *ws, int64_t *out_ids, int out_off, void *logits, float *margin_out,
+                    void *stream);
 
 /* GEMM with the residual epilogue (o_proj / down_proj / fc, model/dflash.py:101,140,144,177):
  *   v = bf16(x W^T);  h_io[m][n] <- add_residual ? bf16(h_io[m][n] + v) : v;

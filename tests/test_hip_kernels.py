@@ -140,6 +140,31 @@ def test_gemm_argmax(ops, V, K, bs):
     assert torch.equal(ids, ids2)
 
 
+@pytest.mark.parametrize("V,K,bs", [(2048, 512, 16), (4096 + 16 * 7, 1024, 9), (151936, 4096, 16)])
+def test_gemm_argmax_margins(ops, V, K, bs):
+    """Top-1 minus top-2 logit per row (the reference's confidence statistic,
+    benchmark_candidate_solutions.py:296-302) from the fused kernel == torch.topk(2) on the
+    bf16 logits the same kernel materialises; duplicated rows give exact ties (margin 0)."""
+    g = gen(V + 1)
+    w = (torch.randn(V, K, generator=g) * 0.02).to(BF16).to(dev())
+    x = torch.randn(16, K, generator=g).to(BF16).to(dev())
+    wp = ops.pack_weight(w)
+    ids = torch.full((16,), -1, dtype=torch.long, device=dev())
+    mg = torch.full((16,), -1.0, dtype=torch.float32, device=dev())
+    logits = torch.zeros(16, V, dtype=BF16, device=dev())
+    ops.gemm_argmax(wp, to_frag(ops, x), V, K, 1, bs - 1, ops.argmax_ws(dev()), ids, 1, logits=logits, margins=mg)
+    top2 = torch.topk(logits[1:bs].float(), 2, dim=-1).values
+    assert torch.equal(mg[1:bs], top2[:, 0] - top2[:, 1])
+    assert torch.equal(ids[1:bs], torch.argmax(logits[1:bs], dim=-1))
+    assert (mg[bs:] == -1).all() and float(mg[0]) == -1
+    # make the winner of every row a duplicated weight row: the runner-up ties, margin 0
+    w2 = w.clone()
+    for r in range(1, bs):
+        w2[(int(ids[r]) + V // 2) % V] = w2[int(ids[r])]
+    ops.gemm_argmax(ops.pack_weight(w2), to_frag(ops, x), V, K, 1, bs - 1, ops.argmax_ws(dev()), ids, 1, margins=mg)
+    assert (mg[1:bs] == 0).all()
+
+
 def test_gemm_argmax_forced_tie(ops):
     V, K = 2048, 512
     w = torch.zeros(V, K, dtype=BF16)
