@@ -13,11 +13,13 @@
 // spinning, nothing to deadlock — sums them in a fixed order and runs the epilogue.
 // Request r reads its rows at base + r * stride and its lengths from dyn + 8 r.
 #include "gemm_rows.h"
+#include <type_traits>
 
 namespace {
 
 struct GemmBArgs {
   const bf16x8 *wp;  // packed weights [ntiles][KS][64]
+  int wp_bytes;
   RowSrc src;        // request 0; request r at the strides below
   int64_t frag_stride, rows_stride, ss_stride;  // in elements of the respective buffers
   const int32_t *dyn;  // [R][DFL_DYN_WORDS]
@@ -69,6 +71,11 @@ template <int MT, int EPI>
 __global__ __launch_bounds__(512) void k_gemm_b(GemmBArgs a) {
   constexpr int FR = 8, NW = 8;
   constexpr int TPU = EPI == EPI_SILU ? 2 : 1;  // tiles per epilogue unit (SILU: gate + up)
+  // MT = 4 lives at the 256-VGPR limit in its main loop (128 activations + 96 weights + 16
+  // accumulators): the epilogue code is kept out of that loop — even a single K part goes
+  // through its slab and the combine phase, where the streaming registers are dead — or hipcc
+  // spills a weight fragment right after loading it (vmcnt(0) in the prefetch ring).
+  constexpr bool INLINE_EPI = MT < 4;
   __shared__ float red[2][NW][MT][256];
   __shared__ float ssred[MT][NW][16];
   __shared__ int s_last;
@@ -107,11 +114,20 @@ __global__ __launch_bounds__(512) void k_gemm_b(GemmBArgs a) {
     return EPI == EPI_SILU ? 2 * ((int)blockIdx.x + (j >> 1) * stride) + (j & 1) : (int)blockIdx.x + j * stride;
   };
 
+  // Weights through buffer loads: descriptor and tile offset in SGPRs, one constant VGPR lane
+  // offset, k-step offsets in the immediate field — no 64-bit VGPR address per fragment.  (With
+  // global loads the MT = 4 kernels sat at 256 VGPRs and hipcc spilled the eighth fragment of a
+  // weight buffer right after loading it: `s_waitcnt vmcnt(0); scratch_store` in the main loop,
+  // which serialises the whole prefetch ring.)
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16x8 *>(a.wp), 0, a.wp_bytes, 0x00020000);
+  const int wvoff = l * 16;
   auto load_item = [&](bf16x8(&wr)[FR], int t) {
-    const bf16x8 *base = a.wp + ((size_t)t * a.KS + ks0) * 64 + l;
+    const int soff = (t * a.KS + ks0) * 1024;  // bytes; < 2^31 checked on the host
 #pragma unroll
     for (int f = 0; f < FR; ++f)
-      if (f < nf0) wr[f] = ld_stream(base + (size_t)f * 64);
+      if (f < nf0)
+        wr[f] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff + (f & 3) * 1024,
+                                                                               soff + (f >> 2) * 4096, 2 /* nt */));
   };
 
   bf16x8 wA[FR], wB[FR], wC[FR];
@@ -254,7 +270,7 @@ __global__ __launch_bounds__(512) void k_gemm_b(GemmBArgs a) {
       for (int ww = 0; ww < NW; ++ww) s += *reinterpret_cast<const f32x4 *>(&red[buf][ww][w][l * 4]);
       if (EPI == EPI_F32) {
         *reinterpret_cast<f32x4 *>(a.out + ((size_t)(ky * MT + w) * 16 + fm) * a.ldo + t * 16 + 4 * fg) = s;
-      } else if (nky > 1) {
+      } else if (nky > 1 || !INLINE_EPI) {
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, s), part_rsrc, slab_off(ky, t, w), 0, 16);  // sc1
       } else if (EPI == EPI_SILU) {
         if ((pos & 1) == 0)
@@ -279,7 +295,7 @@ __global__ __launch_bounds__(512) void k_gemm_b(GemmBArgs a) {
     process(wC, tile_of(j + 2), j + 2);
   }
 
-  if (EPI != EPI_F32 && nky > 1) {
+  if (EPI != EPI_F32 && (nky > 1 || !INLINE_EPI)) {
     // ---- the K parts of this column group meet: sc1 slabs are drained by every storing wave,
     // then ONE relaxed agent-scope ticket; the last part to arrive combines
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -296,7 +312,9 @@ __global__ __launch_bounds__(512) void k_gemm_b(GemmBArgs a) {
     }
     __syncthreads();
     if (!s_last) return;
-    // items = (unit, request), dealt round-robin to the 8 waves; UB of a wave's items in flight
+    // items = (unit, request), dealt round-robin to the 8 waves; UB of a wave's items in flight.
+    // (Tried: batches sized to the wave's item count and two K parts per round — slower, 16.8 ->
+    // 19.5 us on o_proj at 4 tiles; the simple form stays.)
     constexpr int UB = 8;
     const int nitems = (nseq / TPU) * MT;
     const float *pbase = a.part + 4 * l;
@@ -475,6 +493,11 @@ bool fill_batch(GemmBArgs &a, const void *wp, const dfl_rows_batch *x, int R, in
     return false;
   }
   a.wp = (const bf16x8 *)wp;
+  if ((int64_t)N * K * 2 >= ((int64_t)1 << 31)) {
+    dfl_set_error("%s: weight of %lld bytes exceeds the 2 GiB buffer-descriptor range", who, (long long)N * K * 2);
+    return false;
+  }
+  a.wp_bytes = (int)((int64_t)N * K * 2);
   a.frag_stride = x->frag_stride;
   a.rows_stride = x->rows_stride;
   a.ss_stride = x->ss_stride;

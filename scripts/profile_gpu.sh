@@ -23,6 +23,16 @@ elif [ "$mode" = pmc ]; then
     [ $rc -ne 0 ] && { tail -5 "$R/gpurun_out/pmc_$c.err"; exit $rc; }
   done
 fi
+if [ "$mode" = pmcb ]; then   # the ragged batch (4 requests per GPU)
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf "$R/gpurun_out/pmc_${c}_b4"
+    timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$R/gpurun_out/pmc_${c}_b4" -- \
+      python3 "$R/bench.py" --steps 6 --warmup 1 --no-cpu-baseline --target-layers 8 --requests-per-gpu 4 > "$R/gpurun_out/pmc_${c}_b4.json" 2> "$R/gpurun_out/pmc_${c}_b4.err"
+    rc=$?
+    echo "pmcb $c rc=$rc"
+    [ $rc -ne 0 ] && { tail -5 "$R/gpurun_out/pmc_${c}_b4.err"; exit $rc; }
+  done
+fi
 ls -R "$R/gpurun_out" | head -40
 if [ "$mode" = mfma ]; then
   rm -rf "$R/gpurun_out/pmc_mfma"
