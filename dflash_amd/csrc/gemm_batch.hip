@@ -19,7 +19,6 @@ namespace {
 
 struct GemmBArgs {
   const bf16x8 *wp;  // packed weights [ntiles][KS][64]
-  int wp_bytes;
   RowSrc src;        // request 0; request r at the strides below
   int64_t frag_stride, rows_stride, ss_stride;  // in elements of the respective buffers
   const int32_t *dyn;  // [R][DFL_DYN_WORDS]
@@ -114,21 +113,11 @@ __global__ __launch_bounds__(512) void k_gemm_b(GemmBArgs a) {
     return EPI == EPI_SILU ? 2 * ((int)blockIdx.x + (j >> 1) * stride) + (j & 1) : (int)blockIdx.x + j * stride;
   };
 
-  // Weights through buffer loads: descriptor and tile offset in SGPRs, one constant VGPR lane
-  // offset, k-step offsets in the immediate field — no 64-bit VGPR address per fragment.  (With
-  // global loads the MT = 4 kernels sat at 256 VGPRs and hipcc spilled the eighth fragment of a
-  // weight buffer right after loading it: `s_waitcnt vmcnt(0); scratch_store` in the main loop,
-  // which serialises the whole prefetch ring.)
-  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16x8 *>(a.wp), 0, a.wp_bytes, 0x00020000);
-  const int wvoff = l * 16;
-  auto load_item = [&](bf16x8(&wr)[FR], int t) {
-    const int soff = (t * a.KS + ks0) * 1024;  // bytes; < 2^31 checked on the host
-#pragma unroll
-    for (int f = 0; f < FR; ++f)
-      if (f < nf0)
-        wr[f] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff + (f & 3) * 1024,
-                                                                               soff + (f >> 2) * 4096, 2 /* nt */));
-  };
+  // Weights through buffer loads clipped at the wave's share (gemm_rows.h).  With global loads
+  // the MT = 4 kernels sat at 256 VGPRs and hipcc spilled the eighth fragment of a weight buffer
+  // right after loading it: `s_waitcnt vmcnt(0); scratch_store` in the main loop, which
+  // serialises the whole prefetch ring.
+  auto load_item = [&](bf16x8(&wr)[FR], int t) { load_ksteps<FR>(wr, a.wp + ((size_t)t * a.KS + ks0) * 64, nf0, l); };
 
   bf16x8 wA[FR], wB[FR], wC[FR];
   if (nseq > 0) load_item(wA, tile_of(0));  // the first weights leave for HBM before the prologue
@@ -254,12 +243,10 @@ __global__ __launch_bounds__(512) void k_gemm_b(GemmBArgs a) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int f = 0; f < FR; ++f)
-      if (f < nf0) {
+    for (int f = 0; f < FR; ++f)  // k-steps past the wave's share: zero weights and zero activations
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[f], xr[mt][f], acc[mt], 0, 0, 0);
-      }
+      for (int mt = 0; mt < MT; ++mt)
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[f], xr[mt][f], acc[mt], 0, 0, 0);
     const int buf = pos & 1;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f32x4 *>(&red[buf][w][mt][l * 4]) = acc[mt];
@@ -493,11 +480,6 @@ bool fill_batch(GemmBArgs &a, const void *wp, const dfl_rows_batch *x, int R, in
     return false;
   }
   a.wp = (const bf16x8 *)wp;
-  if ((int64_t)N * K * 2 >= ((int64_t)1 << 31)) {
-    dfl_set_error("%s: weight of %lld bytes exceeds the 2 GiB buffer-descriptor range", who, (long long)N * K * 2);
-    return false;
-  }
-  a.wp_bytes = (int)((int64_t)N * K * 2);
   a.frag_stride = x->frag_stride;
   a.rows_stride = x->rows_stride;
   a.ss_stride = x->ss_stride;

@@ -21,6 +21,24 @@ struct RowSrc {
 
 __device__ __forceinline__ bf16x8 ld_stream(const bf16x8 *p) { return __builtin_nontemporal_load(p); }
 
+// Up to NF consecutive k-steps (1 KiB each, wave-wide) of a packed column tile, starting at
+// `first` (= tile base + ks0 * 64), as buffer loads: the descriptor (first, nf KiB) sits in
+// SGPRs, the lane offset is one constant VGPR, k-step offsets go to the immediate / scalar
+// offset fields — no 64-bit VGPR address per fragment.  A k-step >= nf (past the wave's share
+// or past K) is outside the descriptor's range: it returns ZERO and costs no memory traffic,
+// so neither the loads nor the MFMAs that consume them need a guard (guards around loads make
+// hipcc wait vmcnt(0) per fragment; zero weights add zero).
+template <int NF>
+__device__ __forceinline__ void load_ksteps(bf16x8 (&wr)[NF], const bf16x8 *first, int nf, int l) {
+  const __amdgpu_buffer_rsrc_t r =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16x8 *>(first), 0, (nf < 0 ? 0 : nf) * 1024, 0x00020000);
+  const int voff = l * 16;
+#pragma unroll
+  for (int f = 0; f < NF; ++f)
+    wr[f] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff + (f & 3) * 1024, (f >> 2) * 4096,
+                                                                            2 /* nt: streamed once */));
+}
+
 // sum over the 16 lanes of a DPP row, result in each of them
 __device__ __forceinline__ float row_sum16(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));

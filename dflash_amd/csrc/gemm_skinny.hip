@@ -55,8 +55,19 @@ struct GemmArgs {
   float *ss_out;  // [ntiles][16] sum over the tile's 16 columns of h_new^2
 };
 
+#ifdef DFL_GEMM_STAMPS  // diagnostic build only (scripts/dbg_gemm_stamps.py): 100 MHz wall stamps of workgroup 0
+__device__ unsigned long long g_gstamps[8];
+#define GSTAMP(i)                                                                         \
+  do {                                                                                    \
+    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_gstamps[i] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define GSTAMP(i)
+#endif
+
 template <int MT, bool CHUNKED, int EPI>
 __global__ __launch_bounds__(1024) void k_gemm(GemmArgs a) {
+  GSTAMP(0);
   constexpr int FR = CHUNKED ? 4 : (MT == 1 ? 8 : 4);
   // red[buf][wave][mt][256]: lane l owns floats 4l..4l+3 (its MFMA D regs)
   __shared__ float red[2][16][MT][256];
@@ -65,13 +76,19 @@ __global__ __launch_bounds__(1024) void k_gemm(GemmArgs a) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l = tid & 63;
 
-  // ---- row validity (rows >= dyn[valid_word] count as zero)
+  // ---- row validity (rows >= dyn[valid_word] count as zero).  Read AFTER the first weight
+  // loads have been issued (single-chunk kernels): the weights' addresses depend on kernel
+  // arguments only, and waiting for dyn first kept HBM idle for the first 1.5-2.5 us of every
+  // launch (scripts/dbg_gemm_stamps.py).
   int nv[MT];
+  auto read_nv = [&]() {
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const RowSrc &s0 = a.src[mt];
-    nv[mt] = (s0.valid_word >= 0 && a.dyn) ? a.dyn[s0.valid_word] : 16;
-  }
+    for (int mt = 0; mt < MT; ++mt) {
+      const RowSrc &s0 = a.src[mt];
+      nv[mt] = (s0.valid_word >= 0 && a.dyn) ? a.dyn[s0.valid_word] : 16;
+    }
+  };
+  if (CHUNKED) read_nv();  // the chunked kernel builds its activations inside load_item
 
   auto ks0_of = [&](int c) { return ((blockIdx.y * a.nch + c) * 16 + w) * a.nfr; };
   auto nf_of = [&](int c) {
@@ -102,33 +119,25 @@ __global__ __launch_bounds__(1024) void k_gemm(GemmArgs a) {
   int bestn = 0x7fffffff;
   float second = -INFINITY;  // runner-up VALUE as torch.topk(2) defines it: a tie with the best counts
   float gate_sum = 0.f;    // SILU: the pair's gate sum, kept across one position
-  int arg_rows = 0;
-  if (EPI == EPI_ARGMAX) {
-    arg_rows = a.nrows;
-    if (a.dyn && a.nrows_word >= 0) arg_rows = a.dyn[a.nrows_word] - a.row0;
-  }
+  int arg_rows = 0;  // set after the first weight loads, like nv
 
-  // Guards on the k-step count must be loop-invariant or absent: a per-item runtime guard
-  // makes hipcc branch around every fragment load and wait vmcnt(0) after each (49 full
-  // waits instead of 16 in the SILU kernel, 34 -> 41 us).  Single-chunk kernels use the
-  // wave's fixed nf0; the chunked kernel loads unconditionally from a clamped k-step and
-  // feeds zero activations past the end of K (finite weight x 0 = 0).
+  // No guards on the k-step count anywhere: a runtime guard makes hipcc branch around every
+  // fragment load and wait vmcnt(0) after each (49 full waits instead of 16 in the SILU kernel,
+  // 34 -> 41 us).  load_ksteps clips at the wave's share through the buffer descriptor instead
+  // (zero weights, no traffic), and activations past the share are zero as well.
   const int nf0 = nf_of(0);
   auto load_item = [&](bf16x8(&wr)[FR], bf16x8(&xb)[MT][FR], int t, int c) {
     if (!CHUNKED) {
-      const bf16x8 *base = a.wp + ((size_t)t * a.KS + ks0_of(0)) * 64 + l;
-#pragma unroll
-      for (int f = 0; f < FR; ++f)
-        if (f < nf0) wr[f] = ld_stream(base + (size_t)f * 64);
+      load_ksteps<FR>(wr, a.wp + ((size_t)t * a.KS + ks0_of(0)) * 64, nf0, l);
     } else {
       const int ks0 = ks0_of(c);
+      load_ksteps<FR>(wr, a.wp + ((size_t)t * a.KS + ks0) * 64, nf_of(c), l);
       int ks[FR];
       bool take[FR];
 #pragma unroll
       for (int f = 0; f < FR; ++f) {
         take[f] = ks0 + f < a.KS;
         ks[f] = take[f] ? ks0 + f : a.KS - 1;
-        wr[f] = ld_stream(a.wp + ((size_t)t * a.KS + ks[f]) * 64 + l);
       }
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) build_x<FR>(a.src[mt], ks, take, l, nv[mt], 1.f, xb[mt]);
@@ -196,12 +205,10 @@ __global__ __launch_bounds__(1024) void k_gemm(GemmArgs a) {
       for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
-    for (int f = 0; f < FR; ++f)
-      if (CHUNKED || f < nf0) {
+    for (int f = 0; f < FR; ++f)  // k-steps past the wave's share carry zero weights AND zero activations
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[f], CHUNKED ? xb[mt][f] : xr[mt][f], acc[mt], 0, 0, 0);
-      }
+      for (int mt = 0; mt < MT; ++mt)
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[f], CHUNKED ? xb[mt][f] : xr[mt][f], acc[mt], 0, 0, 0);
     if (!CHUNKED || c == a.nch - 1) finish(t, pos);
   };
 
@@ -210,6 +217,15 @@ __global__ __launch_bounds__(1024) void k_gemm(GemmArgs a) {
   bf16x8 xA[MT][FR], xB[MT][FR];
   const int nitems = nseq * a.nch;
   if (nitems > 0) load_item(wA, xA, tile_of(0), 0);  // first weights leave for HBM before the prologue
+  // ... and the second item's too (single-chunk kernels): a workgroup of the 256/384-tile GEMMs
+  // has 1-3 items, so this puts (almost) all of its bytes in flight before the first dependent load
+  if (!CHUNKED && nitems > 1) load_item(wB, xB, tile_of(1), 0);
+  GSTAMP(1);
+  if (!CHUNKED) read_nv();
+  if (EPI == EPI_ARGMAX) {
+    arg_rows = a.nrows;
+    if (a.dyn && a.nrows_word >= 0) arg_rows = a.dyn[a.nrows_word] - a.row0;
+  }
 
   // ---- (mode 2) the rows' rstd, computed while the first weights are in flight.  The nss partial sums of squares of a
   // row are summed by the 16 waves together: wave w takes partials w, w+16, ... with four
@@ -253,6 +269,7 @@ __global__ __launch_bounds__(1024) void k_gemm(GemmArgs a) {
       }
   }
 
+  GSTAMP(2);
   if (!CHUNKED) {
     int ks[FR];
     bool take[FR];
@@ -261,10 +278,28 @@ __global__ __launch_bounds__(1024) void k_gemm(GemmArgs a) {
       take[f] = f < nf0;
       ks[f] = take[f] ? ks0_of(0) + f : 0;
     }
+    // in two halves: the normed source holds raw rows + norm weights of a whole call in
+    // registers, and with two weight buffers in flight a full-width call spilled one of them
+    constexpr int HF = FR / 2;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) build_x<FR>(a.src[mt], ks, take, l, nv[mt], rstd[mt], xr[mt]);
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        int ksh[HF];
+        bool takeh[HF];
+        bf16x8 xh[HF];
+#pragma unroll
+        for (int f = 0; f < HF; ++f) {
+          ksh[f] = ks[hf * HF + f];
+          takeh[f] = take[hf * HF + f];
+        }
+        build_x<HF>(a.src[mt], ksh, takeh, l, nv[mt], rstd[mt], xh);
+#pragma unroll
+        for (int f = 0; f < HF; ++f) xr[mt][hf * HF + f] = xh[f];
+      }
   }
 
+  GSTAMP(3);
   if (nitems > 0) {
     int j = 0, c = 0;  // current item
     for (int i = 0;; i += 2) {
@@ -273,8 +308,9 @@ __global__ __launch_bounds__(1024) void k_gemm(GemmArgs a) {
         cn = 0;
         ++jn;
       }
-      if (i + 1 < nitems) load_item(wB, xB, tile_of(jn), cn);
+      if (i + 1 < nitems && (CHUNKED || i > 0)) load_item(wB, xB, tile_of(jn), cn);  // i == 0: in flight already
       process(wA, xA, tile_of(j), c, j);
+      if (i == 0) GSTAMP(4);
       if (i + 1 >= nitems) break;
       int j2 = jn, c2 = cn + 1;  // item i+2
       if (c2 == a.nch) {
@@ -289,6 +325,7 @@ __global__ __launch_bounds__(1024) void k_gemm(GemmArgs a) {
     }
   }
 
+  GSTAMP(5);
   if (EPI == EPI_ARGMAX) {
     // the 16 threads of row m are consecutive lanes: shuffle down to lane nl == 0
     if (tid < 256) {
@@ -393,6 +430,12 @@ __global__ __launch_bounds__(256) void k_embed_rows(const bf16_t *embed, const i
 }
 
 }  // namespace
+
+#ifdef DFL_GEMM_STAMPS
+extern "C" int dfl_debug_read_gemm_stamps(unsigned long long *host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gstamps), sizeof(unsigned long long) * 8);
+}
+#endif
 
 extern "C" int dfl_pack_weight(const void *w, void *wp, int N, int K, void *stream) {
   DFL_REQUIRE(w && wp, "dfl_pack_weight: null pointer");
