@@ -76,7 +76,6 @@ __global__ __launch_bounds__(512) void k_gemm_b(GemmBArgs a) {
   // spills a weight fragment right after loading it (vmcnt(0) in the prefetch ring).
   constexpr bool INLINE_EPI = MT < 4;
   __shared__ float red[2][NW][MT][256];
-  __shared__ float ssred[MT][NW][16];
   __shared__ int s_last;
 
   const int tid = threadIdx.x;
@@ -92,7 +91,6 @@ __global__ __launch_bounds__(512) void k_gemm_b(GemmBArgs a) {
     src[mt] = a.src;
     if (a.src.frag) src[mt].frag = a.src.frag + (mt * a.frag_stride) / 8;
     if (a.src.rows) src[mt].rows = a.src.rows + mt * a.rows_stride;
-    if (a.src.ss) src[mt].ss = a.src.ss + mt * a.ss_stride;
     nv[mt] = (a.src.valid_word >= 0 && a.dyn) ? a.dyn[mt * DFL_DYN_WORDS + a.src.valid_word] : 16;
   }
 
@@ -119,46 +117,14 @@ __global__ __launch_bounds__(512) void k_gemm_b(GemmBArgs a) {
   // serialises the whole prefetch ring.
   auto load_item = [&](bf16x8(&wr)[FR], int t) { load_ksteps<FR>(wr, a.wp + ((size_t)t * a.KS + ks0) * 64, nf0, l); };
 
-  bf16x8 wA[FR], wB[FR], wC[FR];
-  if (nseq > 0) load_item(wA, tile_of(0));  // the first weights leave for HBM before the prologue
-  if (nseq > 1) load_item(wB, tile_of(1));
-
-  // ---- (mode 2) rstd of every request's rows: the nss partial sums of squares of a row are
-  // summed by the waves together, then exchanged through LDS in a fixed order
-  float rstd[MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) rstd[mt] = 1.f;
-  if (a.src.mode == 2) {
-    const int m = l & 15, part = l >> 4;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      float t = 0.f;
-      for (int base = 0; base < a.src.nss; base += NW * 16) {
-        float v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int i = base + w + NW * (part + 4 * u);
-          v[u] = src[mt].ss[(i < a.src.nss ? i : a.src.nss - 1) * 16 + m];
-          v[u] = i < a.src.nss ? v[u] : 0.f;
-        }
-        t += (v[0] + v[1]) + (v[2] + v[3]);
-      }
-      t += __shfl_xor(t, 16, 64);
-      t += __shfl_xor(t, 32, 64);
-      if (part == 0) ssred[mt][w][m] = t;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      float t = 0.f;
-#pragma unroll
-      for (int ww = 0; ww < NW; ++ww) t += ssred[mt][ww][l & 15];
-      rstd[mt] = rsqrtf(t / (float)(a.KS * 32) + a.src.eps);
-    }
-  }
-
-  // ---- this wave's K slice of every request's tile stays in registers for the launch
+  // ---- prologue: the first two weight items leave for HBM, then this wave's K slice of every
+  // request's tile (it stays in registers for the launch).  Unlike the single-request kernel the
+  // activations go SECOND here: at 4 tiles they are 256 KB per workgroup, and asking for them
+  // first delays the weight stream by more than it saves (6.47 -> 6.69 ms per 4-request cycle).
   bf16x8 xr[MT][FR];
+  bf16x8 wA[FR], wB[FR], wC[FR];
+  if (nseq > 0) load_item(wA, tile_of(0));
+  if (nseq > 1) load_item(wB, tile_of(1));
   {
     int ks[FR];
     bool take[FR];
@@ -168,7 +134,7 @@ __global__ __launch_bounds__(512) void k_gemm_b(GemmBArgs a) {
       ks[f] = take[f] ? ks0 + f : 0;
     }
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) build_x<FR>(src[mt], ks, take, l, nv[mt], rstd[mt], xr[mt]);
+    for (int mt = 0; mt < MT; ++mt) build_x<FR, false>(src[mt], ks, take, l, nv[mt], 1.f, xr[mt]);
   }
 
   // ---- epilogue state of this lane, per request
@@ -475,6 +441,10 @@ bool fill_batch(GemmBArgs &a, const void *wp, const dfl_rows_batch *x, int R, in
     return false;
   }
   if (!fill_src(a.src, &x->r0, K, who)) return false;
+  if (x->r0.mode == 2) {  // 128x redundant in every workgroup and ~10 us of VALU at 4 tiles: not offered here
+    dfl_set_error("%s: the batched GEMMs take normalised rows from dfl_norm_frag_batch (mode 0), not mode 2", who);
+    return false;
+  }
   if ((x->r0.valid_word >= 0 && !dyn) || x->frag_stride % 8) {
     dfl_set_error("%s: row validity needs dyn; frag_stride must be a multiple of 8", who);
     return false;

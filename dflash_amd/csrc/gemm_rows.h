@@ -49,37 +49,69 @@ __device__ __forceinline__ float row_sum16(float v) {
 }
 
 // B-operand fragments of k-steps ks[0..NF) for lane l (m = l&15, kq = l>>4):
-// x[m][ks*32 + kq*8 .. +8].  `take[f]` false -> zero fragment (k-step past the wave's
-// share or past K; ks[f] is then any valid step).  The source mode is switched OUTSIDE the
-// fragment loop so that the loads of one call are issued together; branching per fragment
-// serialised them with a vmcnt(0) each (8 L2 round trips, +6.5 us per launch, measured).
-template <int NF>
-__device__ __forceinline__ void build_x(const RowSrc &s, const int (&ks)[NF], const bool (&take)[NF], int l, int nv,
-                                        float rstd, bf16x8 (&x)[NF]) {
+// x[m][ks*32 + kq*8 .. +8], in two steps so that the caller can put its weight loads BETWEEN
+// them: a wave's vector loads return in issue order (vmcnt), so activation loads issued after
+// a weight burst are held back until the burst has landed — and the rstd / normalise chain
+// behind them with it (scripts/dbg_gemm_stamps.py: the prologue then ran AFTER the first
+// burst with HBM idle, 4-5 us per launch).  issue_x: the loads (raw rows or fragments, norm
+// weights); finish_x: mask / normalise.  `take[f]` false -> zero fragment (k-step past the
+// wave's share or past K; ks[f] is then any valid step).  The source mode is switched
+// OUTSIDE the fragment loops so that the loads of one call are issued together; branching
+// per fragment serialised them with a vmcnt(0) each (+6.5 us per launch, measured).
+template <int NF, bool NORM = true>
+__device__ __forceinline__ void issue_x(const RowSrc &s, const int (&ks)[NF], int l, int nv, bf16x8 (&raw)[NF],
+                                        bf16x8 (&wv)[NF]) {
+  // one branch-free load sequence for all modes (a mode branch around the loads made hipcc keep
+  // the fragment arrays in scratch memory): per-lane base + k-step stride, both by select
+  const int m = l & 15, kq = l >> 4;
+  const int mr = m < nv ? m : (nv > 0 ? nv - 1 : 0);  // never read past the caller's valid rows
+  const bool fr = s.mode == 0;
+  const char *base = fr ? reinterpret_cast<const char *>(s.frag) + l * 16
+                        : reinterpret_cast<const char *>(s.rows) + ((int64_t)mr * s.ld + kq * 8) * 2;
+  const int kstep = fr ? 1024 : 64;  // bytes per k-step: a 64-lane fragment / 32 bf16 of a row
+  // norm weights: only mode 2 has them; the others read (and ignore) 16 B of their own operand
+  const char *nwb = s.mode == 2 ? reinterpret_cast<const char *>(s.nw) + kq * 16 : base;
+  const int nstep = s.mode == 2 ? 64 : kstep;
+#pragma unroll
+  for (int f = 0; f < NF; ++f) raw[f] = *reinterpret_cast<const bf16x8 *>(base + (int64_t)ks[f] * kstep);
+  if (NORM) {  // compile-time: kernels that never see mode 2 skip these loads
+#pragma unroll
+    for (int f = 0; f < NF; ++f) wv[f] = *reinterpret_cast<const bf16x8 *>(nwb + (int64_t)ks[f] * nstep);
+  }
+}
+
+template <int NF, bool NORM = true>
+__device__ __forceinline__ void finish_x(const RowSrc &s, const bool (&take)[NF], int l, int nv, float rstd,
+                                         const bf16x8 (&raw)[NF], const bf16x8 (&wv)[NF], bf16x8 (&x)[NF]) {
   const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
   if (s.mode == 0) {
 #pragma unroll
-    for (int f = 0; f < NF; ++f) x[f] = s.frag[(size_t)ks[f] * 64 + l];
-#pragma unroll
-    for (int f = 0; f < NF; ++f) x[f] = take[f] ? x[f] : z;
+    for (int f = 0; f < NF; ++f) x[f] = take[f] ? raw[f] : z;
     return;
   }
-  const int m = l & 15, kq = l >> 4;
-  const int mr = m < nv ? m : (nv > 0 ? nv - 1 : 0);  // never read past the caller's valid rows
-  const bf16_t *row = s.rows + (int64_t)mr * s.ld + kq * 8;
+  const int m = l & 15;
+  const bool norm = NORM && s.mode == 2;  // Qwen3RMSNorm: weight * bf16(x * rstd), tf:modeling_qwen3.py:59-64
 #pragma unroll
-  for (int f = 0; f < NF; ++f) x[f] = *reinterpret_cast<const bf16x8 *>(row + ks[f] * 32);
-  if (s.mode == 2) {  // Qwen3RMSNorm: weight * bf16(x * rstd), tf:modeling_qwen3.py:59-64
-    bf16x8 wv[NF];
+  for (int f = 0; f < NF; ++f) {
+    const bf16x8 r = raw[f];  // whole-vector copies: element access through the array
+    bf16x8 o = r;             // reference kept the arrays in scratch memory
+    if (norm) {
+      const bf16x8 wq = wv[f];
 #pragma unroll
-    for (int f = 0; f < NF; ++f) wv[f] = *reinterpret_cast<const bf16x8 *>(s.nw + ks[f] * 32 + kq * 8);
-#pragma unroll
-    for (int f = 0; f < NF; ++f)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) x[f][j] = f2bf(bf2f(wv[f][j]) * rbf(bf2f(x[f][j]) * rstd));
+      for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(wq[j]) * rbf(bf2f(r[j]) * rstd));
+    }
+    x[f] = (take[f] && m < nv) ? o : z;
   }
+}
+
+template <int NF, bool NORM = true>
+__device__ __forceinline__ void build_x(const RowSrc &s, const int (&ks)[NF], const bool (&take)[NF], int l, int nv,
+                                        float rstd, bf16x8 (&x)[NF]) {
+  bf16x8 raw[NF], wv[NF];
 #pragma unroll
-  for (int f = 0; f < NF; ++f) x[f] = (take[f] && m < nv) ? x[f] : z;
+  for (int f = 0; f < NF; ++f) wv[f] = raw[f] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+  issue_x<NF, NORM>(s, ks, l, nv, raw, wv);
+  finish_x<NF, NORM>(s, take, l, nv, rstd, raw, wv, x);
 }
 
 // ---- host side ----

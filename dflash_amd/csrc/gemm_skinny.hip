@@ -76,10 +76,7 @@ __global__ __launch_bounds__(1024) void k_gemm(GemmArgs a) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l = tid & 63;
 
-  // ---- row validity (rows >= dyn[valid_word] count as zero).  Read AFTER the first weight
-  // loads have been issued (single-chunk kernels): the weights' addresses depend on kernel
-  // arguments only, and waiting for dyn first kept HBM idle for the first 1.5-2.5 us of every
-  // launch (scripts/dbg_gemm_stamps.py).
+  // ---- row validity (rows >= dyn[valid_word] count as zero): a scalar load, on its own counter
   int nv[MT];
   auto read_nv = [&]() {
 #pragma unroll
@@ -119,7 +116,7 @@ __global__ __launch_bounds__(1024) void k_gemm(GemmArgs a) {
   int bestn = 0x7fffffff;
   float second = -INFINITY;  // runner-up VALUE as torch.topk(2) defines it: a tie with the best counts
   float gate_sum = 0.f;    // SILU: the pair's gate sum, kept across one position
-  int arg_rows = 0;  // set after the first weight loads, like nv
+  int arg_rows = 0;
 
   // No guards on the k-step count anywhere: a runtime guard makes hipcc branch around every
   // fragment load and wait vmcnt(0) after each (49 full waits instead of 16 in the SILU kernel,
@@ -129,9 +126,8 @@ __global__ __launch_bounds__(1024) void k_gemm(GemmArgs a) {
   auto load_item = [&](bf16x8(&wr)[FR], bf16x8(&xb)[MT][FR], int t, int c) {
     if (!CHUNKED) {
       load_ksteps<FR>(wr, a.wp + ((size_t)t * a.KS + ks0_of(0)) * 64, nf0, l);
-    } else {
+    } else {  // activation loads first, then the weights, then the masks (vmcnt is in order)
       const int ks0 = ks0_of(c);
-      load_ksteps<FR>(wr, a.wp + ((size_t)t * a.KS + ks0) * 64, nf_of(c), l);
       int ks[FR];
       bool take[FR];
 #pragma unroll
@@ -139,8 +135,16 @@ __global__ __launch_bounds__(1024) void k_gemm(GemmArgs a) {
         take[f] = ks0 + f < a.KS;
         ks[f] = take[f] ? ks0 + f : a.KS - 1;
       }
+      bf16x8 raw[MT][FR], wv[MT][FR];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) build_x<FR>(a.src[mt], ks, take, l, nv[mt], 1.f, xb[mt]);
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int f = 0; f < FR; ++f) wv[mt][f] = raw[mt][f] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) issue_x<FR>(a.src[mt], ks, l, nv[mt], raw[mt], wv[mt]);
+      load_ksteps<FR>(wr, a.wp + ((size_t)t * a.KS + ks0) * 64, nf_of(c), l);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) finish_x<FR>(a.src[mt], take, l, nv[mt], 1.f, raw[mt], wv[mt], xb[mt]);
     }
   };
 
@@ -216,61 +220,40 @@ __global__ __launch_bounds__(1024) void k_gemm(GemmArgs a) {
   bf16x8 wA[FR], wB[FR];
   bf16x8 xA[MT][FR], xB[MT][FR];
   const int nitems = nseq * a.nch;
-  if (nitems > 0) load_item(wA, xA, tile_of(0), 0);  // first weights leave for HBM before the prologue
-  // ... and the second item's too (single-chunk kernels): a workgroup of the 256/384-tile GEMMs
-  // has 1-3 items, so this puts (almost) all of its bytes in flight before the first dependent load
-  if (!CHUNKED && nitems > 1) load_item(wB, xB, tile_of(1), 0);
-  GSTAMP(1);
-  if (!CHUNKED) read_nv();
-  if (EPI == EPI_ARGMAX) {
-    arg_rows = a.nrows;
-    if (a.dyn && a.nrows_word >= 0) arg_rows = a.dyn[a.nrows_word] - a.row0;
-  }
-
-  // ---- (mode 2) the rows' rstd, computed while the first weights are in flight.  The nss partial sums of squares of a
-  // row are summed by the 16 waves together: wave w takes partials w, w+16, ... with four
-  // unconditional loads in flight per lane (a serial loop over all 256 cost ~20 us of
-  // dependent L2 round trips per launch), then one LDS exchange in a fixed order.
+  // ---- prologue (single-chunk kernels).  Order of issue: lengths (scalar) -> the activation
+  // side's vector loads (sums of squares, rows / fragments, norm weights) -> the first weights.
+  // A wave's vector loads return in issue order, so whatever is requested behind a weight burst
+  // is held back until the burst has landed; asked for first, the few KB of activations arrive
+  // within ~1 us and rstd / normalisation run UNDER the burst.
   __shared__ float ssred[MT][16][16];
   float rstd[MT];
-  bool any_norm = false;
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const RowSrc &s = a.src[mt];
-    rstd[mt] = 1.f;
-    if (s.mode == 2) {
-      any_norm = true;
-      const int m = l & 15, part = l >> 4;
-      float t = 0.f;
-      for (int base = 0; base < s.nss; base += 256) {
-        float v[4];
+  for (int mt = 0; mt < MT; ++mt) rstd[mt] = 1.f;
+  if (!CHUNKED) {
+    read_nv();
+    if (EPI == EPI_ARGMAX) {
+      arg_rows = a.nrows;
+      if (a.dyn && a.nrows_word >= 0) arg_rows = a.dyn[a.nrows_word] - a.row0;
+    }
+    // (mode 2) the nss partial sums of squares of a row are summed by the 16 waves together:
+    // wave w takes partials w, w+16, ... (four unconditional loads in flight per lane per 256)
+    float ssv[MT][4];
+    bool any_norm = false;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const RowSrc &s = a.src[mt];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) ssv[mt][u] = 0.f;
+      if (s.mode == 2) {
+        any_norm = true;
+        const int m = l & 15, part = l >> 4;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const int i = base + w + 16 * (part + 4 * u);
-          v[u] = s.ss[(i < s.nss ? i : s.nss - 1) * 16 + m];
-          v[u] = i < s.nss ? v[u] : 0.f;
+          const int i = w + 16 * (part + 4 * u);
+          ssv[mt][u] = s.ss[(i < s.nss ? i : s.nss - 1) * 16 + m];
         }
-        t += (v[0] + v[1]) + (v[2] + v[3]);
       }
-      t += __shfl_xor(t, 16, 64);
-      t += __shfl_xor(t, 32, 64);
-      if (part == 0) ssred[mt][w][m] = t;
     }
-  }
-  if (any_norm) {  // uniform over the workgroup: the modes are kernel arguments
-    __syncthreads();
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-      if (a.src[mt].mode == 2) {
-        float t = 0.f;
-#pragma unroll
-        for (int ww = 0; ww < 16; ++ww) t += ssred[mt][ww][l & 15];
-        rstd[mt] = rsqrtf(t / (float)(a.KS * 32) + a.src[mt].eps);
-      }
-  }
-
-  GSTAMP(2);
-  if (!CHUNKED) {
     int ks[FR];
     bool take[FR];
 #pragma unroll
@@ -278,25 +261,61 @@ __global__ __launch_bounds__(1024) void k_gemm(GemmArgs a) {
       take[f] = f < nf0;
       ks[f] = take[f] ? ks0_of(0) + f : 0;
     }
-    // in two halves: the normed source holds raw rows + norm weights of a whole call in
-    // registers, and with two weight buffers in flight a full-width call spilled one of them
-    constexpr int HF = FR / 2;
+    bf16x8 raw[MT][FR], wv[MT][FR];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        int ksh[HF];
-        bool takeh[HF];
-        bf16x8 xh[HF];
+      for (int f = 0; f < FR; ++f) wv[mt][f] = raw[mt][f] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int f = 0; f < HF; ++f) {
-          ksh[f] = ks[hf * HF + f];
-          takeh[f] = take[hf * HF + f];
+    for (int mt = 0; mt < MT; ++mt) issue_x<FR>(a.src[mt], ks, l, nv[mt], raw[mt], wv[mt]);
+    if (nitems > 0) load_item(wA, xA, tile_of(0), 0);  // the first weights, behind the activations
+    GSTAMP(1);
+    if (any_norm) {  // uniform over the workgroup: the modes are kernel arguments
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const RowSrc &s = a.src[mt];
+        if (s.mode == 2) {
+          const int m = l & 15, part = l >> 4;
+          float v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] = (w + 16 * (part + 4 * u)) < s.nss ? ssv[mt][u] : 0.f;
+          float t = (v[0] + v[1]) + (v[2] + v[3]);
+          for (int base = 256; base < s.nss; base += 256) {  // more than 256 partials: rare, late loads
+            float v2[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int i = base + w + 16 * (part + 4 * u);
+              v2[u] = s.ss[(i < s.nss ? i : s.nss - 1) * 16 + m];
+              v2[u] = i < s.nss ? v2[u] : 0.f;
+            }
+            t += (v2[0] + v2[1]) + (v2[2] + v2[3]);
+          }
+          t += __shfl_xor(t, 16, 64);
+          t += __shfl_xor(t, 32, 64);
+          if (part == 0) ssred[mt][w][m] = t;
         }
-        build_x<HF>(a.src[mt], ksh, takeh, l, nv[mt], rstd[mt], xh);
-#pragma unroll
-        for (int f = 0; f < HF; ++f) xr[mt][hf * HF + f] = xh[f];
       }
+      __syncthreads();
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        if (a.src[mt].mode == 2) {
+          float t = 0.f;
+#pragma unroll
+          for (int ww = 0; ww < 16; ++ww) t += ssred[mt][ww][l & 15];
+          rstd[mt] = rsqrtf(t / (float)(a.KS * 32) + a.src[mt].eps);
+        }
+    }
+    GSTAMP(2);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) finish_x<FR>(a.src[mt], take, l, nv[mt], rstd[mt], raw[mt], wv[mt], xr[mt]);
+  } else {
+    if (EPI == EPI_ARGMAX) {
+      arg_rows = a.nrows;
+      if (a.dyn && a.nrows_word >= 0) arg_rows = a.dyn[a.nrows_word] - a.row0;
+    }
+    if (nitems > 0) load_item(wA, xA, tile_of(0), 0);
+    GSTAMP(1);
+    GSTAMP(2);
   }
 
   GSTAMP(3);
@@ -308,7 +327,7 @@ __global__ __launch_bounds__(1024) void k_gemm(GemmArgs a) {
         cn = 0;
         ++jn;
       }
-      if (i + 1 < nitems && (CHUNKED || i > 0)) load_item(wB, xB, tile_of(jn), cn);  // i == 0: in flight already
+      if (i + 1 < nitems) load_item(wB, xB, tile_of(jn), cn);
       process(wA, xA, tile_of(j), c, j);
       if (i == 0) GSTAMP(4);
       if (i + 1 >= nitems) break;

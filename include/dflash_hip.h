@@ -230,7 +230,8 @@ int dfl_accept_commit(const int64_t *block_ids, const int64_t *posterior, int bs
  * requests; the unused ones need valid (readable) memory and dyn words of zero.
  * ====================================================================================== */
 typedef struct dfl_rows_batch {
-  dfl_rows r0;          /* request 0, as for the single-request GEMMs */
+  dfl_rows r0;          /* request 0: mode 0 (frag16) or 1 (plain rows); mode 2 is rejected — take
+                         * normalised rows from dfl_norm_frag_batch */
   int64_t frag_stride;  /* bf16 elements between the requests' frag16 buffers (mode 0), %8 == 0 */
   int64_t rows_stride;  /* bf16 elements between the requests' row buffers (mode 1, 2) */
   int64_t ss_stride;    /* floats between the requests' sum-of-squares partials (mode 2) */

@@ -253,31 +253,38 @@ def test_gemm_argmax_batch(R, V, K, row0):
         assert torch.all(ids[r, row0 + n:] == -1) and torch.all(ids[r, :row0] == -1)
 
 
-def test_gemm_f32_batch_and_normed_source():
-    """fp32 partial output over the K parts + the RMSNorm row source (sum-of-squares
-    partials left by a producer): sum of the parts equals the reference GEMM of the
-    normalised rows."""
+def test_norm_frag_then_gemm_f32_batch():
+    """dfl_norm_frag_batch (RMSNorm -> frag16, per-request valid rows) feeding the fp32 partial
+    GEMM over the K parts: sum of the parts equals the reference GEMM of the normalised rows;
+    the batched GEMMs reject the in-GEMM norm source (mode 2)."""
     from dflash_amd import ops
+    from dflash_amd._lib import DFlashHipError
     R, N, K = 3, 6144, 4096
     MT = ops.batch_tiles(R)
     g = _gen(5)
     w = (torch.randn(N, K, generator=g) * 0.05).to(BF16).to(dev())
     h = torch.randn(MT, 16, K, generator=g).to(BF16).to(dev())
     nw = (1 + 0.1 * torch.randn(K, generator=g)).to(BF16).to(dev())
-    ss = h.float().pow(2).view(MT, 16, K // 16, 16).sum(-1).permute(0, 2, 1).contiguous().view(MT, K)  # [tile][row]
     dyn = _dyn([(0, 16), (0, 9), (0, 2), (0, 0)], MT)
+    xn = torch.full((MT, 16 * K), 7.0, dtype=BF16, device=dev())
+    ops.norm_frag_batch(h, R, nw, 1e-6, xn, dyn, ops.DYN_BS)
     ks = ops.batch_ksplit(K)
     out = torch.zeros(ks * MT * 16 * N, dtype=torch.float32, device=dev())
-    ops.gemm_f32_batch(ops.pack_weight(w), ops.brows_normed(h, ss, K // 16, nw, 1e-6, ops.DYN_BS), R, N, K, out, dyn)
+    wp = ops.pack_weight(w)
+    ops.gemm_f32_batch(wp, ops.brows_frag(xn), R, N, K, out, dyn)
     got = out.view(ks, MT, 16, N).sum(0)
     for r, nv in enumerate([16, 9, 2]):
         hf = h[r].float()
-        xn = (nw.float() * (hf * torch.rsqrt(hf.pow(2).mean(-1, keepdim=True) + 1e-6)).to(BF16).float()).to(BF16).float()
-        want = xn @ w.float().T
-        want[nv:] = 0
+        xr = (nw.float() * (hf * torch.rsqrt(hf.pow(2).mean(-1, keepdim=True) + 1e-6)).to(BF16).float()).to(BF16)
+        xr[nv:] = 0
+        assert torch.equal(_unfrag(xn[r], K), xr), r          # same rounding points as Qwen3RMSNorm
+        want = xr.float() @ w.float().T
         d = (got[r] - want).abs()
         assert d.max() <= 1e-2 * want.abs().max(), r
         assert torch.count_nonzero(got[r, nv:]) == 0
+    ss = torch.ones(MT, K, device=dev())
+    with pytest.raises(DFlashHipError):
+        ops.gemm_f32_batch(wp, ops.brows_normed(h, ss, K // 16, nw, 1e-6, ops.DYN_BS), R, N, K, out, dyn)
 
 
 def test_graph_replay_matches_eager_cycles():
