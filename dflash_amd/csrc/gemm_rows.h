@@ -63,11 +63,13 @@ __device__ __forceinline__ void issue_x(const RowSrc &s, const int (&ks)[NF], in
                                         bf16x8 (&wv)[NF]) {
   // one branch-free load sequence for all modes (a mode branch around the loads made hipcc keep
   // the fragment arrays in scratch memory): per-lane base + k-step stride, both by select
+  // All 16 rows are loaded, valid or not (the caller's buffer covers 16 rows, dflash_hip.h):
+  // no address depends on `nv`, so nothing here waits for the scalar load of the lengths.
+  (void)nv;
   const int m = l & 15, kq = l >> 4;
-  const int mr = m < nv ? m : (nv > 0 ? nv - 1 : 0);  // never read past the caller's valid rows
   const bool fr = s.mode == 0;
   const char *base = fr ? reinterpret_cast<const char *>(s.frag) + l * 16
-                        : reinterpret_cast<const char *>(s.rows) + ((int64_t)mr * s.ld + kq * 8) * 2;
+                        : reinterpret_cast<const char *>(s.rows) + ((int64_t)m * s.ld + kq * 8) * 2;
   const int kstep = fr ? 1024 : 64;  // bytes per k-step: a 64-lane fragment / 32 bf16 of a row
   // norm weights: only mode 2 has them; the others read (and ignore) 16 B of their own operand
   const char *nwb = s.mode == 2 ? reinterpret_cast<const char *>(s.nw) + kq * 16 : base;

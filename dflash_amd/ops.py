@@ -83,10 +83,23 @@ def rows_frag(frag: torch.Tensor) -> RowSource:
     return RowSource(Rows(_p(frag, BF16, "frag"), None, 0, None, 0, None, 0.0, -1, 0), frag)
 
 
+def _readable16(rows: torch.Tensor) -> torch.Tensor:
+    """The kernels load all 16 rows of a tile before they know how many are valid (the lengths
+    arrive by a scalar load they do not wait for): the storage behind `rows` must cover 16
+    rows.  A view of a 16-row buffer does; a shorter tensor is copied into a padded one."""
+    need = (15 * rows.stride(0) + rows.shape[1]) * rows.element_size()
+    have = rows.untyped_storage().nbytes() - rows.storage_offset() * rows.element_size()
+    if rows.shape[0] >= 16 or have >= need:
+        return rows
+    pad = torch.zeros(16, rows.shape[1], dtype=rows.dtype, device=rows.device)
+    pad[:rows.shape[0]] = rows
+    return pad
+
+
 def rows_plain(rows: torch.Tensor, valid_word: int = -1) -> RowSource:
-    """bf16 rows [<=16, K] (unit inner stride); rows >= dyn[valid_word] count as zero.
-    The buffer must hold 16 readable rows."""
+    """bf16 rows [<=16, K] (unit inner stride); rows >= dyn[valid_word] count as zero."""
     assert rows.is_cuda and rows.dtype == BF16 and rows.dim() == 2 and rows.stride(1) == 1
+    rows = _readable16(rows)
     return RowSource(Rows(None, rows.data_ptr(), rows.stride(0), None, 0, None, 0.0, valid_word, 1), rows)
 
 
@@ -95,6 +108,7 @@ def rows_normed(rows: torch.Tensor, ss: torch.Tensor, nss: int, norm_w: torch.Te
     """the residual stream + partial sums of squares: the GEMM applies the RMSNorm itself."""
     assert rows.is_cuda and rows.dtype == BF16 and rows.dim() == 2 and rows.stride(1) == 1
     assert ss.numel() >= nss * 16
+    rows = _readable16(rows)
     return RowSource(Rows(None, rows.data_ptr(), rows.stride(0), _p(ss, F32, "ss"), nss, _p(norm_w, BF16, "norm_w"),
                           eps, valid_word, 2), rows, ss, norm_w)
 

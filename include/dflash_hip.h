@@ -56,7 +56,9 @@ extern "C" {
 
 /* Where one 16-row activation tile of a GEMM comes from.
  *  mode 0  frag   : frag16 fragments [K/8][16][8] written by a producer kernel;
- *  mode 1  rows   : plain bf16 rows [16][K] with row stride ld (e.g. the target taps);
+ *  mode 1  rows   : plain bf16 rows [16][K] with row stride ld (e.g. the target taps); all 16
+ *                   rows must be READABLE memory (they are loaded before the valid count is known
+ *                   and masked afterwards), whatever dyn[valid_word] says;
  *  mode 2  normed : rows = the residual stream h (a buffer of 16 readable rows), and the GEMM applies the RMSNorm while
  *                   it builds its fragments: x = norm_w * bf16(h * rsqrt(sum_i ss[i][m] / K
  *                   + eps)) (Qwen3RMSNorm, tf:models/qwen3/modeling_qwen3.py:59-64), where
