@@ -74,13 +74,16 @@ class NativeTarget:
         theta = (rope.get("rope_theta") if isinstance(rope, dict) else None) or getattr(cfg, "rope_theta", None)
         if self.hd != 128 or self.H // 32 > 128 or self.H % 32 or self.I % 32 or self.V % 16:
             raise NotImplementedError("NativeTarget: needs head_dim 128, hidden <= 4096 (%32), vocab %16")
-        if rtype != "default" or theta is None:
+        # position-only RoPE variants: the cos/sin tables are taken from the wrapped model's own
+        # rotary module (Llama-3.1's "llama3" frequency scaling, BASELINE config 4; linear; yarn)
+        if rtype not in ("default", "llama3", "linear", "yarn") or (rtype == "default" and theta is None):
             raise NotImplementedError(f"NativeTarget: rope_type {rtype!r} is not supported; keep the HF target")
+        self.rope_type = rtype
         if getattr(cfg, "num_experts", 0) or getattr(cfg, "num_local_experts", 0):
             raise NotImplementedError("NativeTarget: MoE targets stay on the HF path")
         if getattr(cfg, "attention_bias", False) or getattr(cfg, "mlp_bias", False):
             raise NotImplementedError("NativeTarget: biased projections are not supported")
-        self.theta = float(theta)
+        self.theta = float(theta) if theta is not None else None
         sd = hf_model.state_dict()
 
         def w(name):
@@ -147,7 +150,12 @@ class NativeTarget:
     def _rope_tab(self, need: int):
         if self._rope is None or self._rope[0].shape[0] < need:
             n = 1 << (max(need, 4096) - 1).bit_length()
-            self._rope = _rope_tables(128, self.theta, n, self._dev)
+            if self.rope_type == "default":
+                self._rope = _rope_tables(128, self.theta, n, self._dev)
+            else:  # what the wrapped model itself multiplies by (scaled frequencies, attention factor), in bf16
+                pos = torch.arange(n, device=self._dev).unsqueeze(0)
+                cos, sin = self.model.rotary_emb(torch.zeros(1, dtype=BF16, device=self._dev), pos)
+                self._rope = (cos[0, :, :64].to(BF16).contiguous(), sin[0, :, :64].to(BF16).contiguous())
         return self._rope
 
     # ---- prefill through the wrapped model, K/V copied into the preallocated cache

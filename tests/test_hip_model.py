@@ -336,16 +336,20 @@ def test_from_pretrained_checkpoint_dir(tmp_path):
             assert torch.equal(la[k], lb[k]), k
 
 
-def test_native_target_llama_style():
-    """BASELINE config 4's target family (Llama: no per-head q/k norm, rope_type default
-    here): NativeTarget verify vs the HF forward."""
+@pytest.mark.parametrize("rope", [{"rope_type": "default", "rope_theta": 500000.0},
+                                  {"rope_type": "llama3", "rope_theta": 500000.0, "factor": 8.0, "low_freq_factor": 1.0,
+                                   "high_freq_factor": 4.0, "original_max_position_embeddings": 32}])
+def test_native_target_llama_style(rope):
+    """BASELINE config 4's target family (Llama-3.1: no per-head q/k norm, "llama3" RoPE
+    frequency scaling — made active at test positions by a small original context):
+    NativeTarget verify vs the HF forward."""
     tf = pytest.importorskip("transformers")
     from transformers import DynamicCache
     from dflash_amd import NativeTarget
     cfg = tf.LlamaConfig(vocab_size=2048, hidden_size=512, intermediate_size=1024, num_hidden_layers=4,
                          num_attention_heads=4, num_key_value_heads=2, head_dim=128, rms_norm_eps=1e-5,
                          max_position_embeddings=4096, tie_word_embeddings=False, attention_bias=False,
-                         mlp_bias=False, rope_parameters={"rope_type": "default", "rope_theta": 500000.0})
+                         mlp_bias=False, rope_parameters=dict(rope))
     cfg._attn_implementation = "sdpa"
     torch.manual_seed(3)
     prev = torch.get_default_dtype()
@@ -373,6 +377,9 @@ def test_native_target_llama_style():
     r = ref.hidden_states[2][0].float()
     assert (taps[:12, :512].float() - r).abs().max() <= 4e-2 * r.abs().max()
     assert torch.equal(post[0], torch.argmax(logits[:12], dim=-1))
+    for got, want in ((cache.k[0][:, :41], rc.layers[0].keys[0]), (cache.k[3][:, :41], rc.layers[3].keys[0])):
+        d = (got.float() - want.float()).abs()   # K rows carry the RoPE: scaled frequencies included
+        assert d.max() <= 6e-2 * want.float().abs().max() and d.mean() <= 4e-3 * want.float().abs().max()
 
 
 def test_full_size_draft_cycle_matches_oracle():
