@@ -46,7 +46,8 @@ class BatchedDecoder:
     """Device state and per-cycle launch sequence of one group of R <= 4 requests."""
 
     def __init__(self, model: DFlashDraftModel, target: NativeTarget, n_requests: int, max_rows: int,
-                 out_len: int, mask_token_id: int, stop_token_ids=None, max_splits: int = 32):
+                 out_len: int, mask_token_id: int, stop_token_ids=None, max_splits: int = 32,
+                 temperature: float = 0.0):
         if not isinstance(target, NativeTarget):
             raise TypeError("BatchedDecoder needs a dflash_amd.NativeTarget (see module docstring)")
         if not 1 <= n_requests <= MAX_GROUP:
@@ -61,6 +62,8 @@ class BatchedDecoder:
         self.dev = dev = model.device
         self.max_rows, self.out_len, self.mask_id = int(max_rows), int(out_len), int(mask_token_id)
         self.max_splits = max_splits
+        self.temperature = float(temperature)
+        self._logits = None
         R, MT, H, I = self.R, self.MT, c.hidden_size, c.intermediate_size
         z = lambda *s, dt=BF16: torch.zeros(*s, dtype=dt, device=dev)  # noqa: E731
 
@@ -255,8 +258,18 @@ class BatchedDecoder:
             ops.gemm_resid_batch(lw["down"], s["act"], R, H, t.I, tt["h"], add_residual=True, ws=self.gws,
                                  dyn=self.dyn_t, tap=tap)
         ops.norm_frag_batch(tt["h"], R, t.norm, t.eps, tt["xn"], self.dyn_t, ops.DYN_BS)
-        ops.gemm_argmax_batch(self.lm_wp, s["xn"], R, t.V, H, 0, 16, self.gws, self.post, 0, self.dyn_t,
-                              nrows_dyn_word=ops.DYN_BS)
+        if self.temperature < 1e-5:
+            ops.gemm_argmax_batch(self.lm_wp, s["xn"], R, t.V, H, 0, 16, self.gws, self.post, 0, self.dyn_t,
+                                  nrows_dyn_word=ops.DYN_BS)
+        else:
+            # T > 0 (model/utils.py:30-34): the same GEMM materialises the bf16 logits and the
+            # reference's own softmax + torch.multinomial draws the posterior (caller's RNG stream;
+            # one draw over all requests' rows, so the stream differs from R sequential runs)
+            if self._logits is None:
+                self._logits = torch.zeros(MT, 16, t.V, dtype=BF16, device=self.dev)
+            ops.gemm_argmax_batch(self.lm_wp, s["xn"], R, t.V, H, 0, 16, self.gws, self.post, 0, self.dyn_t,
+                                  nrows_dyn_word=ops.DYN_BS, logits=self._logits)
+            self.post[:R] = sample(self._logits[:R], self.temperature)
 
     def _accept_launch(self) -> None:
         ops.accept_commit_batch(self.block, self.post, self.R, self.output_ids, self.dyn_d, self.dyn_t, self.stop_t,
@@ -345,8 +358,6 @@ def dflash_generate_batch(model: DFlashDraftModel, target: NativeTarget, input_i
     groups of `group_size` <= 4 that share the weight stream; returns one namespace per
     prompt with the fields of benchmark.py:242-251 (timing fields are the group's).
     draft_token_hook(request_index, block, start, call)."""
-    if temperature >= 1e-5:
-        raise NotImplementedError("the batched loop is greedy (T = 0); use dflash_generate for T > 0")
     if block_size != 16:
         raise NotImplementedError("the batched kernels take 16-row blocks")
     n = len(input_ids)
@@ -358,7 +369,7 @@ def dflash_generate_batch(model: DFlashDraftModel, target: NativeTarget, input_i
         max_len = [p.shape[1] + max_new_tokens for p in prompts]
         dec = BatchedDecoder(model, target, len(idx), max_rows=pmax + max_new_tokens + 3 * 16,
                              out_len=pmax + max_new_tokens + 16, mask_token_id=mask_token_id,
-                             stop_token_ids=stop_token_ids)
+                             stop_token_ids=stop_token_ids, temperature=temperature)
         t0 = cuda_time()
         for r, p in enumerate(prompts):
             dec.admit(r, p, temperature)

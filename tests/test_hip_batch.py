@@ -91,6 +91,28 @@ def test_batch_stop_token_parks_one_request():
     assert outs[1].output_ids[0, -1].item() == stop[0] or stop[0] in Gs[1][:44].tolist()
 
 
+def test_batch_temperature_path_with_sharp_logits():
+    """T = 0.7 in the batched loop (BASELINE config 4's sampling rule: a draft token is accepted
+    iff it equals the token SAMPLED from the target, model/utils.py:30-34): the walk target's
+    logit margin (~70) makes the draw deterministic, so ids and acceptance lengths equal T = 0."""
+    from dflash_amd.batch import dflash_generate_batch
+    from dflash_amd.synthetic import greedy_walk
+    cfg, m, hf, nt, perm = _setup()
+    lens, n_new = (30, 17), 40
+    prompts = [torch.randint(0, 2000, (1, P), generator=torch.Generator().manual_seed(60 + i)).to(dev())
+               for i, P in enumerate(lens)]
+    Gs = [greedy_walk(perm, p, n_new + 40).to(dev()) for p in prompts]
+    plans = [H.make_plan(64, 16, 33 + i) for i in range(2)]
+    hooks = [_hook_for(Gs[i], plans[i]) for i in range(2)]
+    bh = lambda i, blk, s, c: hooks[i](blk[:, :min(16, lens[i] + n_new - s)], s, c)  # noqa: E731
+    cold = dflash_generate_batch(m, nt, prompts, cfg.mask_token_id, n_new, 16, None, 0.0, draft_token_hook=bh)
+    torch.manual_seed(0)
+    warm = dflash_generate_batch(m, nt, prompts, cfg.mask_token_id, n_new, 16, None, 0.7, draft_token_hook=bh)
+    for i in range(2):
+        assert warm[i].output_ids[0].tolist() == cold[i].output_ids[0].tolist() == Gs[i][:lens[i] + n_new].tolist()
+        assert warm[i].acceptance_lengths == cold[i].acceptance_lengths
+
+
 def test_batched_draft_and_verify_match_single_kernels():
     """Three cycles, 3 requests with different prefix lengths, interleaved with three
     single-request sessions on the same target: committed ids and tau exact; draft ids,
