@@ -63,7 +63,7 @@ SIGNATURES = {
     "dfl_gemm_resid_batch": (_i, [_p, _rb, _i, _i, _i, _p, _i64, _i64, _i, _p, _i64, _i64, _p, _i64, _p, _p, _p]),
     "dfl_gemm_argmax_batch": (_i, [_p, _rb, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i64, _i, _p, _i64, _p]),
     "dfl_embed_rows_batch": (_i, [_p, _p, _i64, _i, _p, _i64, _i, _p, _i64, _p, _i, _p]),
-    "dfl_norm_frag_batch": (_i, [_p, _i64, _i64, _i, _p, _f, _p, _i64, _i, _p, _i, _p]),
+    "dfl_norm_frag_batch": (_i, [_p, _i64, _i64, _i, _p, _i, _i64, _i, _p, _i64, _i64, _p, _f, _p, _i64, _i, _p, _i, _p]),
     "dfl_kv_append_batch": (_i, [_p, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i64, _f, _p, _p, _i, _p, _p, _i,
                                  _i64, _i64, _p, _p]),
     "dfl_attn_fused_batch_ws_bytes": (_i64, [_i, _i, _i, _i]),

@@ -86,7 +86,7 @@ class BatchedDecoder:
         self.d = dict(h=z(MT, 16, H), ctxh=z(MT, 16, H), ss_emb=z(MT, 16, dt=F32), xn=z(MT, 16 * H),
                       attn=z(MT, 16 * c.q_dim), act=z(MT, 16 * I),
                       part_qkv=z(ks(H) * MT * 16 * self.nqkv_d, dt=F32), part_kv=z(ks(H) * MT * 16 * self.nkv_all, dt=F32),
-                      taps=z(MT, 16, c.fc_in))
+                      part_h=z(max(ks(c.q_dim), ks(I)) * MT * 16 * H, dt=F32), taps=z(MT, 16, c.fc_in))
         # context K/V weights of all layers as ONE packed weight: the k/v column tiles of each
         # layer's packed qkv, concatenated (tile-major layout: a plain cat of tile ranges)
         L = model.w["layers"]
@@ -95,7 +95,8 @@ class BatchedDecoder:
         # ---- target scratch
         self.nqkv_t = t.nqkv
         self.t = dict(h=z(MT, 16, H), ss_emb=z(MT, 16, dt=F32), xn=z(MT, 16 * H), attn=z(MT, 16 * t.q_dim),
-                      act=z(MT, 16 * t.I), part_qkv=z(ks(H) * MT * 16 * t.nqkv, dt=F32))
+                      act=z(MT, 16 * t.I), part_qkv=z(ks(H) * MT * 16 * t.nqkv, dt=F32),
+                      part_h=z(max(ks(t.q_dim), ks(t.I)) * MT * 16 * H, dt=F32))
         # ---- shared workspaces (launches are stream-ordered)
         nmax = max(c.vocab_size, t.V, 2 * I, 2 * t.I)
         kmax = max(H, I, t.I, c.fc_in, c.q_dim)
@@ -206,9 +207,12 @@ class BatchedDecoder:
                             v_col=c.kv_dim, col_layer_stride=2 * c.kv_dim, n_layers=c.num_hidden_layers, R=R,
                             n_kv=c.num_key_value_heads, k_norm_w=self.k_norm_all, eps=c.rms_norm_eps, cos_tab=cos,
                             sin_tab=sin, kcache=self.dk, vcache=self.dv, dyn=self.dyn_d)
-        # block rows
+        # block rows.  o_proj / down_proj leave fp32 K-part sums; the residual add happens in the
+        # norm launch that follows (the parts meet at the launch boundary, not inside the GEMM)
+        pend = 0  # K of the GEMM whose sums are waiting in part_h (0: none)
         for i, lw in enumerate(L):
-            ops.norm_frag_batch(d["h"], R, lw["ln1"], eps, d["xn"], self.dyn_t, ops.DYN_BS)
+            ops.norm_frag_batch(d["h"], R, lw["ln1"], eps, d["xn"], self.dyn_t, ops.DYN_BS,
+                                part=d["part_h"] if pend else None, N=H, K=pend)
             ops.gemm_f32_batch(lw["qkv"], s["xn"], R, self.nqkv_d, H, d["part_qkv"], self.dyn_t)
             ops.attn_fused_batch(qkv=d["part_qkv"], nsplit=nsp, split_stride=MT * 16 * self.nqkv_d, ld=self.nqkv_d,
                                  q_col=0, k_col=c.q_dim, v_col=c.q_dim + c.kv_dim, R=R, n_q=c.num_attention_heads,
@@ -216,16 +220,17 @@ class BatchedDecoder:
                                  eps=c.rms_norm_eps, cos_tab=cos, sin_tab=sin, kcache=self.dk, vcache=self.dv, layer=i,
                                  scale=c.head_dim ** -0.5, causal=False, dyn=self.dyn_t, kv_len_max=kvmax,
                                  ws=self.aws_d, max_splits=self.max_splits, out_frag=d["attn"])
-            ops.gemm_resid_batch(lw["o"], s["attn"], R, H, c.q_dim, d["h"], add_residual=True, ws=self.gws,
-                                 dyn=self.dyn_t)
-            ops.norm_frag_batch(d["h"], R, lw["ln2"], eps, d["xn"], self.dyn_t, ops.DYN_BS)
+            ops.gemm_f32_batch(lw["o"], s["attn"], R, H, c.q_dim, d["part_h"], self.dyn_t)
+            ops.norm_frag_batch(d["h"], R, lw["ln2"], eps, d["xn"], self.dyn_t, ops.DYN_BS, part=d["part_h"], N=H,
+                                K=c.q_dim)
             ops.gemm_silu_mul_batch(lw["gu"], s["xn"], R, I, H, d["act"], self.gws, self.dyn_t)
-            ops.gemm_resid_batch(lw["down"], s["act"], R, H, I, d["h"], add_residual=True, ws=self.gws,
-                                 dyn=self.dyn_t)
+            ops.gemm_f32_batch(lw["down"], s["act"], R, H, I, d["part_h"], self.dyn_t)
+            pend = I
 
     def _draft_head(self) -> None:
         m, c, d, s, R = self.model, self.cfg, self.d, self.src_d, self.R
-        ops.norm_frag_batch(d["h"], R, m.w["norm"], c.rms_norm_eps, d["xn"], self.dyn_t, ops.DYN_BS)
+        ops.norm_frag_batch(d["h"], R, m.w["norm"], c.rms_norm_eps, d["xn"], self.dyn_t, ops.DYN_BS,
+                            part=d["part_h"], N=c.hidden_size, K=c.intermediate_size)  # last down_proj + final norm
         ops.gemm_argmax_batch(self.lm_wp, s["xn"], R, c.vocab_size, c.hidden_size, 1, 15, self.gws, self.block, 1,
                               self.dyn_t, nrows_dyn_word=ops.DYN_BS)
 
@@ -241,8 +246,10 @@ class BatchedDecoder:
             raise NotImplementedError("tapping the last layer (post-norm state) is not supported")
         nsp = ops.batch_ksplit(H)
         ops.embed_rows_batch(t.embed, self.block, R, tt["h"], H, tt["ss_emb"], self.dyn_t, ops.DYN_BS)
+        pend, ptap = 0, None  # K and tap view of the down_proj whose sums wait in part_h
         for i, lw in enumerate(t.layers):
-            ops.norm_frag_batch(tt["h"], R, lw["ln1"], t.eps, tt["xn"], self.dyn_t, ops.DYN_BS)
+            ops.norm_frag_batch(tt["h"], R, lw["ln1"], t.eps, tt["xn"], self.dyn_t, ops.DYN_BS,
+                                part=tt["part_h"] if pend else None, N=H, K=pend, tap=ptap)
             ops.gemm_f32_batch(lw["qkv"], s["xn"], R, t.nqkv, H, tt["part_qkv"], self.dyn_t)
             ops.attn_fused_batch(qkv=tt["part_qkv"], nsplit=nsp, split_stride=MT * 16 * t.nqkv, ld=t.nqkv, q_col=0,
                                  k_col=t.q_dim, v_col=t.q_dim + t.kv_dim, R=R, n_q=t.n_q, n_kv=t.n_kv,
@@ -250,14 +257,16 @@ class BatchedDecoder:
                                  kcache=self.tk, vcache=self.tv, layer=i, scale=128 ** -0.5, causal=True,
                                  dyn=self.dyn_t, kv_len_max=kvmax, ws=self.aws_t, max_splits=self.max_splits,
                                  out_frag=tt["attn"])
-            ops.gemm_resid_batch(lw["o"], s["attn"], R, H, t.q_dim, tt["h"], add_residual=True, ws=self.gws,
-                                 dyn=self.dyn_t)
-            ops.norm_frag_batch(tt["h"], R, lw["ln2"], t.eps, tt["xn"], self.dyn_t, ops.DYN_BS)
+            ops.gemm_f32_batch(lw["o"], s["attn"], R, H, t.q_dim, tt["part_h"], self.dyn_t)
+            ops.norm_frag_batch(tt["h"], R, lw["ln2"], t.eps, tt["xn"], self.dyn_t, ops.DYN_BS, part=tt["part_h"],
+                                N=H, K=t.q_dim)
             ops.gemm_silu_mul_batch(lw["gu"], s["xn"], R, t.I, H, tt["act"], self.gws, self.dyn_t)
-            tap = taps[:, :, tl.index(i) * H:(tl.index(i) + 1) * H] if i in tl else None
-            ops.gemm_resid_batch(lw["down"], s["act"], R, H, t.I, tt["h"], add_residual=True, ws=self.gws,
-                                 dyn=self.dyn_t, tap=tap)
-        ops.norm_frag_batch(tt["h"], R, t.norm, t.eps, tt["xn"], self.dyn_t, ops.DYN_BS)
+            ops.gemm_f32_batch(lw["down"], s["act"], R, H, t.I, tt["part_h"], self.dyn_t)
+            # the layer's output (a tapped layer's hidden rows, model/utils.py:16-25) exists once the
+            # next norm launch has added these sums: it writes the tap
+            pend, ptap = t.I, (taps[:, :, tl.index(i) * H:(tl.index(i) + 1) * H] if i in tl else None)
+        ops.norm_frag_batch(tt["h"], R, t.norm, t.eps, tt["xn"], self.dyn_t, ops.DYN_BS, part=tt["part_h"], N=H, K=pend,
+                            tap=ptap)
         if self.temperature < 1e-5:
             ops.gemm_argmax_batch(self.lm_wp, s["xn"], R, t.V, H, 0, 16, self.gws, self.post, 0, self.dyn_t,
                                   nrows_dyn_word=ops.DYN_BS)

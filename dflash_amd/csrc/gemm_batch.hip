@@ -380,14 +380,22 @@ __global__ __launch_bounds__(256) void k_embed_rows_b(const bf16_t *embed, const
   if (tid == 0) ss_out[r * ss_stride + m] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-// frag[r] <- norm_w * bf16(h[r][m] * rsqrt(mean(h^2) + eps)) as frag16 (Qwen3RMSNorm,
-// tf:models/qwen3/modeling_qwen3.py:59-64), rows >= dyn valid count zeroed.  grid (16, R).
-// Batched GEMMs take normalised rows from here rather than normalising in their prologue:
-// that prologue runs in every workgroup (128x redundant) and at 4 request tiles costs ~10 us
-// of VALU per launch (scripts/bench_gemm_batch.py: qkv 25.6 us normed source vs 15.2 us frag).
-__global__ __launch_bounds__(256) void k_norm_frag_b(const bf16_t *h, int64_t h_stride, int64_t ldh,
-                                                     const bf16_t *nw, float eps, bf16x8 *frag,
-                                                     int64_t frag_stride8, int H, const int32_t *dyn, int dyn_word) {
+// Residual add + RMSNorm -> frag16 for R requests, grid (16, R):
+//   h[r][m] <- part ? bf16(h + bf16(sum_k part[k][r*16+m][:])) : h     (model/dflash.py:140,144)
+//   tap[r][m] <- the new h row (optional: a tapped target layer, model/utils.py:16-25)
+//   frag[r]  <- norm_w * bf16(h * rsqrt(mean(h^2) + eps))               (tf:modeling_qwen3.py:59-64)
+// rows >= dyn valid count: frag zeroed, h untouched.  `part` = the fp32 K-part sums of the
+// o_proj / down_proj GEMM that ran just before (dfl_gemm_f32_batch): their K parts meet HERE, at
+// the launch boundary — this kernel reads every h row anyway — instead of through slabs + ticket
+// inside the GEMM (o_proj 16.8 -> ~12 us, down 33.6 -> ~27 us at 4 tiles; scripts/bench_gemm_batch.py).
+// Batched GEMMs take normalised rows from here rather than normalising in their prologue: that
+// prologue runs in every workgroup (128x redundant) and at 4 request tiles costs ~10 us of VALU
+// per launch (qkv 25.6 us with the normed source vs 15.2 us from frag16).
+__global__ __launch_bounds__(256) void k_norm_frag_b(bf16_t *h, int64_t h_stride, int64_t ldh, const float *part,
+                                                     int nsplit, int64_t part_split, int ldp, bf16_t *tap,
+                                                     int64_t ldtap, int64_t tap_stride, const bf16_t *nw, float eps,
+                                                     bf16x8 *frag, int64_t frag_stride8, int H, const int32_t *dyn,
+                                                     int dyn_word) {
   __shared__ float wsum[4];
   const int m = blockIdx.x, r = blockIdx.y, tid = threadIdx.x;
   const int nv = dyn ? dyn[r * DFL_DYN_WORDS + dyn_word] : 16;
@@ -398,10 +406,29 @@ __global__ __launch_bounds__(256) void k_norm_frag_b(const bf16_t *h, int64_t h_
     for (int c = tid; c < nchunks; c += 256) out[c * 16 + m] = z;
     return;
   }
-  const bf16_t *row = h + r * h_stride + (int64_t)m * ldh;
+  bf16_t *row = h + r * h_stride + (int64_t)m * ldh;
+  const float *prow = part ? part + (int64_t)(r * 16 + m) * ldp : nullptr;
   float ss = 0.f;
   for (int c = tid; c < nchunks; c += 256) {
-    const bf16x8 v = *reinterpret_cast<const bf16x8 *>(row + c * 8);
+    bf16x8 v = *reinterpret_cast<const bf16x8 *>(row + c * 8);
+    if (prow) {
+      float acc[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+      for (int k = 0; k < nsplit; ++k) {  // fixed part order
+        const f32x4 p0 = *reinterpret_cast<const f32x4 *>(prow + k * part_split + c * 8);
+        const f32x4 p1 = *reinterpret_cast<const f32x4 *>(prow + k * part_split + c * 8 + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[j] += p0[j];
+          acc[4 + j] += p1[j];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(v[j]) + rbf(acc[j]));  // Linear output in bf16, then the add
+      *reinterpret_cast<bf16x8 *>(row + c * 8) = v;  // re-read below by this same thread
+    }
+    if (tap) *reinterpret_cast<bf16x8 *>(tap + r * tap_stride + (int64_t)m * ldtap + c * 8) = v;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ss += bf2f(v[j]) * bf2f(v[j]);
   }
@@ -410,7 +437,7 @@ __global__ __launch_bounds__(256) void k_norm_frag_b(const bf16_t *h, int64_t h_
   __syncthreads();
   const float rstd = rsqrtf((wsum[0] + wsum[1] + wsum[2] + wsum[3]) / (float)H + eps);
   for (int c = tid; c < nchunks; c += 256) {
-    const bf16x8 v = *reinterpret_cast<const bf16x8 *>(row + c * 8);  // L1 hit
+    const bf16x8 v = *reinterpret_cast<const bf16x8 *>(row + c * 8);  // own store / L1 hit
     const bf16x8 wv = *reinterpret_cast<const bf16x8 *>(nw + c * 8);
     bf16x8 o;
 #pragma unroll
@@ -573,15 +600,19 @@ extern "C" int dfl_embed_rows_batch(const void *embed, const int64_t *ids, int64
   return DFL_OK;
 }
 
-extern "C" int dfl_norm_frag_batch(const void *h, int64_t h_stride, int64_t ldh, int R, const void *norm_w, float eps,
-                                   void *frag, int64_t frag_stride, int H, const int32_t *dyn, int dyn_word,
-                                   void *stream) {
+extern "C" int dfl_norm_frag_batch(void *h, int64_t h_stride, int64_t ldh, int R, const float *part, int nsplit,
+                                   int64_t part_split, int ldp, void *tap, int64_t ldtap, int64_t tap_stride,
+                                   const void *norm_w, float eps, void *frag, int64_t frag_stride, int H,
+                                   const int32_t *dyn, int dyn_word, void *stream) {
   DFL_REQUIRE(h && norm_w && frag, "dfl_norm_frag_batch: null pointer");
   DFL_REQUIRE(H > 0 && H % 8 == 0 && ldh >= H && ldh % 8 == 0 && frag_stride % 8 == 0 && frag_stride >= 16 * (int64_t)H,
               "dfl_norm_frag_batch: bad shape / strides");
   DFL_REQUIRE(R >= 1 && R <= 4, "dfl_norm_frag_batch: R outside 1..4");
-  hipLaunchKernelGGL(k_norm_frag_b, dim3(16, R), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)h, h_stride, ldh,
-                     (const bf16_t *)norm_w, eps, (bf16x8 *)frag, frag_stride / 8, H, dyn, dyn_word);
+  DFL_REQUIRE(!part || (nsplit >= 1 && ldp >= H && ldp % 4 == 0), "dfl_norm_frag_batch: bad partial layout");
+  DFL_REQUIRE(!tap || (ldtap >= H && ldtap % 8 == 0), "dfl_norm_frag_batch: bad tap layout");
+  hipLaunchKernelGGL(k_norm_frag_b, dim3(16, R), dim3(256), 0, (hipStream_t)stream, (bf16_t *)h, h_stride, ldh, part, nsplit,
+                     part_split, ldp, (bf16_t *)tap, ldtap, tap_stride, (const bf16_t *)norm_w, eps, (bf16x8 *)frag,
+                     frag_stride / 8, H, dyn, dyn_word);
   DFL_CHECK_LAUNCH("dfl_norm_frag_batch");
   return DFL_OK;
 }

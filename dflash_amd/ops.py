@@ -372,12 +372,27 @@ def embed_rows_batch(embed, ids: torch.Tensor, R: int, h_out: torch.Tensor, H: i
 
 
 def norm_frag_batch(h: torch.Tensor, R: int, norm_w: torch.Tensor, eps: float, frag: torch.Tensor, dyn,
-                    dyn_word: int) -> None:
-    """h [MT, 16, H] -> frag [MT, 16*H] = frag16 of the RMS-normalised rows."""
+                    dyn_word: int, part: Optional[torch.Tensor] = None, N: int = 0, K: int = 0,
+                    tap: Optional[torch.Tensor] = None) -> None:
+    """h [MT, 16, H] -> frag [MT, 16*H] = frag16 of the RMS-normalised rows.  part: the fp32
+    partial sums gemm_f32_batch(N=H, K) left ([ksplit][MT*16][H]): added to h first (residual
+    add, in place); tap: optional [MT, 16, *] view receiving the new rows."""
     assert h.dim() == 3 and h.stride(2) == 1 and frag.dim() == 2 and frag.is_contiguous()
-    check(lib().dfl_norm_frag_batch(_p(h[0, 0], BF16, "h"), h.stride(0), h.stride(1), R, _p(norm_w, BF16, "norm_w"), eps,
-                                    _p(frag, BF16, "frag"), frag.stride(0), h.shape[2], _p(dyn, I32, "dyn"), dyn_word,
-                                    _stream()), "dfl_norm_frag_batch")
+    H = h.shape[2]
+    pp, ns, ps, ldp = None, 0, 0, 0
+    if part is not None:
+        assert N == H and K > 0
+        ns, ldp = batch_ksplit(K), N
+        ps = batch_tiles(R) * 16 * N
+        assert part.numel() >= ns * ps
+        pp = _p(part, F32, "part")
+    tp, ldt, tst = None, 0, 0
+    if tap is not None:
+        assert tap.is_cuda and tap.dtype == BF16 and tap.dim() == 3 and tap.stride(2) == 1
+        tp, ldt, tst = tap.data_ptr(), tap.stride(1), tap.stride(0)
+    check(lib().dfl_norm_frag_batch(_p(h[0, 0], BF16, "h"), h.stride(0), h.stride(1), R, pp, ns, ps, ldp, tp, ldt, tst,
+                                    _p(norm_w, BF16, "norm_w"), eps, _p(frag, BF16, "frag"), frag.stride(0), H,
+                                    _p(dyn, I32, "dyn"), dyn_word, _stream()), "dfl_norm_frag_batch")
 
 
 def kv_append_batch(*, kv, nsplit, split_stride, ld, k_col, v_col, col_layer_stride, n_layers, R, n_kv, k_norm_w,

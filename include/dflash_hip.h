@@ -265,13 +265,20 @@ int dfl_embed_rows_batch(const void *embed, const int64_t *ids, int64_t ids_stri
                          int64_t h_stride, int H, float *ss_out, int64_t ss_stride, const int32_t *dyn, int dyn_word,
                          void *stream);
 
-/* RMSNorm of R requests' residual rows straight into frag16 (Qwen3RMSNorm,
- * tf:models/qwen3/modeling_qwen3.py:59-64): frag[r] = norm_w * bf16(h[r] * rstd), rows >=
- * dyn[r][dyn_word] zeroed.  The batched GEMMs read their normalised operand from here (the
- * in-GEMM norm of the single-request path is replicated in every workgroup, which at 4 tiles
- * costs more than this launch). */
-int dfl_norm_frag_batch(const void *h, int64_t h_stride, int64_t ldh, int R, const void *norm_w, float eps, void *frag,
-                        int64_t frag_stride, int H, const int32_t *dyn, int dyn_word, void *stream);
+/* Residual add + RMSNorm of R requests' rows straight into frag16 (model/dflash.py:140,144 +
+ * Qwen3RMSNorm, tf:models/qwen3/modeling_qwen3.py:59-64):
+ *   h[r][m]   <- part ? bf16(h[r][m] + bf16(sum_{k<nsplit} part[k*part_split + (r*16+m)*ldp ..])) : h[r][m]
+ *   tap[r][m] <- that row (optional: a tapped target layer, model/utils.py:16-25)
+ *   frag[r]   <- norm_w * bf16(h * rstd);  rows >= dyn[r][dyn_word]: frag zeroed, h untouched.
+ * `part` = the fp32 K-part sums of the o_proj / down_proj GEMM just before it
+ * (dfl_gemm_f32_batch): the parts meet at this launch boundary — the kernel reads every h row
+ * anyway — instead of inside the GEMM.  The batched GEMMs read their normalised operand from
+ * here (the in-GEMM norm of the single-request path is replicated in every workgroup, which
+ * at 4 tiles costs more than this launch). */
+int dfl_norm_frag_batch(void *h, int64_t h_stride, int64_t ldh, int R, const float *part, int nsplit,
+                        int64_t part_split, int ldp, void *tap, int64_t ldtap, int64_t tap_stride, const void *norm_w,
+                        float eps, void *frag, int64_t frag_stride, int H, const int32_t *dyn, int dyn_word,
+                        void *stream);
 
 /* Context K/V of ALL draft layers for R requests in one launch (model/dflash.py:73-85, the
  * context half): kv = fp32 partials of the context rows times the concatenated k/v weights
