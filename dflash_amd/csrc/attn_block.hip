@@ -741,9 +741,17 @@ int attn_fused_launch(const float *qkv, int nsplit, int64_t split_stride, int ld
               "dfl_attn_fused: bad layout");
   DFL_REQUIRE(kv_len_max > 0 && kv_len_max <= cache_rows && max_splits >= 1, "dfl_attn_fused: bad kv_len_max/max_splits");
   DFL_REQUIRE(R >= 1 && R <= 64, "dfl_attn_fused: R outside 1..64");
-  // ~4 key tiles (128 keys) per split
+  // Key splits: a workgroup's tile loop costs ~1.45 us per 32-key tile, the last arriver's merge
+  // ~0.6 us per split (scripts/dbg_attn_stamps.py), so the stage is shortest for ns ~ sqrt(tiles):
+  // 8 splits at 1k keys (as with the former tiles/4 rule), 15 instead of 32 at 4k keys, where the
+  // stage took 47 us with the linear rule and 35-38 us with this one (constants 1.1-1.55 measure
+  // the same within noise).
   const int ntiles = (kv_len_max + 31) / 32;
-  int ns = ntiles / 4;
+#ifndef DFL_ATTN_NS_C  // swept in scripts/dbg_attn_stamps.py (-DDFL_ATTN_NS_C=...)
+#define DFL_ATTN_NS_C 1.35f
+#endif
+  int ns = (int)(DFL_ATTN_NS_C * sqrtf((float)ntiles) + 0.5f);
+  ns = ns > ntiles ? ntiles : ns;
   ns = ns < 1 ? 1 : (ns > max_splits ? max_splits : ns);
   FusedAttnArgs a{};
   a.qkv = qkv;
