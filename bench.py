@@ -83,7 +83,6 @@ def gpu_leg(args, rank, world, dev):
     from dflash_amd import DFlashConfig, DFlashDraftModel
     from dflash_amd.config import QWEN3_8B_DRAFT
     from dflash_amd.generate import DecodeSession
-    from dflash_amd.synthetic import make_draft_state_dict
 
     torch.manual_seed(0)
     t0 = time.time()

@@ -23,8 +23,8 @@ import torch
 
 from . import ops
 from .generate import _bf16_table, _taps, _trim, cuda_time
-from .model import DFlashDraftModel, DFlashKVCache
-from .target import NativeTarget, TargetKVCache
+from .model import DFlashDraftModel
+from .target import NativeTarget
 from .utils import sample
 
 BF16, F32, I32, I64 = torch.bfloat16, torch.float32, torch.int32, torch.int64

@@ -20,7 +20,6 @@ import torch
 
 from . import ops
 from .config import DFlashConfig
-from .utils import extract_context_feature, sample
 
 BF16 = torch.bfloat16
 

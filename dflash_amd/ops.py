@@ -308,7 +308,8 @@ def brows_plain(rows: torch.Tensor, valid_word: int = -1) -> BatchRowSource:
 
 def brows_normed(rows: torch.Tensor, ss: torch.Tensor, nss: int, norm_w: torch.Tensor, eps: float,
                  valid_word: int = -1) -> BatchRowSource:
-    """rows [MT, 16, K] + ss [MT, >= nss*16]: the GEMM applies the RMSNorm per request."""
+    """rows [MT, 16, K] + ss [MT, >= nss*16] as a mode-2 source.  The batched GEMMs REJECT it
+    (normalised rows come from norm_frag_batch); kept so that the rejection can be tested."""
     assert rows.is_cuda and rows.dtype == BF16 and rows.dim() == 3 and rows.stride(2) == 1
     assert ss.dim() == 2 and ss.shape[1] >= nss * 16 and ss.stride(1) == 1
     r0 = Rows(None, rows.data_ptr(), rows.stride(1), _p(ss[0], F32, "ss"), nss, _p(norm_w, BF16, "norm_w"), eps,

@@ -18,7 +18,6 @@ loops of this package detect it and take the fast path instead:
 """
 from __future__ import annotations
 
-from types import SimpleNamespace
 from typing import Optional, Sequence
 
 import torch

@@ -59,9 +59,6 @@ def run(name, kind, N, K):
         src = ops.brows_plain(x, ops.DYN_BS)
         if os.environ.get("SRC") == "frag":
             src = ops.brows_frag(x.reshape(MT, 16 * K).contiguous())
-        elif os.environ.get("SRC") == "normed":
-            nw = torch.ones(K, device=dev, dtype=BF16)
-            src = ops.brows_normed(x, torch.rand(MT, K, device=dev), K // 16, nw, 1e-6, ops.DYN_BS)
         ws = ops.gemm_batch_ws(2 * N if kind == "silu" else N, K, dev)
         if kind == "f32":
             out = torch.empty(ops.batch_ksplit(K) * MT * 16 * N, device=dev, dtype=torch.float32)
