@@ -160,44 +160,32 @@ __global__ __launch_bounds__(512) void k_block_attn(AttnArgs a) {
 }
 
 // Merge the key splits of NH (head, q, 8-column group) items that differ only in the
-// head (consecutive heads): branch-free, and every load of a split pair is issued before
-// any is used (an empty split has m = -inf, l = 0 and gets weight 0).  Fixed split order,
-// so the sums are reproducible.
+// head (consecutive heads): branch-free, every load of a batch of U splits issued before any
+// is used (an empty split has m = -inf, l = 0 and gets weight 0).  ONE pass with a running
+// maximum (online rescaling, as inside a split) instead of a maximum pass followed by a sum
+// pass: every batch is a dependent ~0.65 us round trip to partials other workgroups wrote, and
+// 9 splits took 3 + 5 rounds (5.4 us of the stage's 20, scripts/dbg_attn_stamps.py); now 3.
+// Fixed split order, so the sums are reproducible.
 template <int NH>
 __device__ __forceinline__ void merge_items(const float *o_part, const float *ml_part, int nsplit, int n_q, int hh0,
                                             int q, int dg, bf16x8 (&out)[NH]) {
+  constexpr int U = 3;  // (U = 4: 247 VGPRs, no faster)
   const int64_t sml = (int64_t)n_q * 16 * 2, so = (int64_t)n_q * 16 * 128;
   const float *ml0 = ml_part + ((int64_t)hh0 * 16 + q) * 2;
   const float *o0 = o_part + ((int64_t)hh0 * 16 + q) * 128 + dg * 8;
-  float M[NH];
-#pragma unroll
-  for (int h = 0; h < NH; ++h) M[h] = -INFINITY;
-  for (int s = 0; s < nsplit; s += 4) {
-    float mv[4][NH];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int sc = s + u < nsplit ? s + u : nsplit - 1;
-#pragma unroll
-      for (int h = 0; h < NH; ++h) mv[u][h] = ml0[sc * sml + h * 32];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int h = 0; h < NH; ++h) M[h] = fmaxf(M[h], mv[u][h]);
-  }
-  float acc[NH][8], L[NH];
+  float M[NH], L[NH], acc[NH][8];
 #pragma unroll
   for (int h = 0; h < NH; ++h) {
-    M[h] = M[h] == -INFINITY ? 0.f : M[h];
+    M[h] = -INFINITY;
     L[h] = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[h][j] = 0.f;
   }
-  for (int s = 0; s < nsplit; s += 2) {
-    float ms[2][NH], ls[2][NH];
-    f32x4 a0[2][NH], a1[2][NH];
+  for (int s = 0; s < nsplit; s += U) {
+    float ms[U][NH], ls[U][NH];
+    f32x4 a0[U][NH], a1[U][NH];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int sc = s + u < nsplit ? s + u : nsplit - 1;
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
@@ -208,10 +196,19 @@ __device__ __forceinline__ void merge_items(const float *o_part, const float *ml
       }
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int h = 0; h < NH; ++h) {
+      float mnew = M[h];
 #pragma unroll
-      for (int h = 0; h < NH; ++h) {
-        const float wgt = s + u < nsplit ? exp2f(ms[u][h] - M[h]) : 0.f;  // exp2(-inf) = 0: empty split
+      for (int u = 0; u < U; ++u) mnew = fmaxf(mnew, s + u < nsplit ? ms[u][h] : -INFINITY);
+      const float mref = mnew == -INFINITY ? 0.f : mnew;
+      const float scale = exp2f(M[h] - mref);  // first batch: exp2(-inf) = 0 on zero sums
+      M[h] = mnew;
+      L[h] *= scale;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[h][j] *= scale;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float wgt = s + u < nsplit ? exp2f(ms[u][h] - mref) : 0.f;  // exp2(-inf) = 0: empty split
         L[h] += wgt * ls[u][h];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -219,6 +216,7 @@ __device__ __forceinline__ void merge_items(const float *o_part, const float *ml
           acc[h][4 + j] += wgt * a1[u][h][j];
         }
       }
+    }
   }
 #pragma unroll
   for (int h = 0; h < NH; ++h) {
