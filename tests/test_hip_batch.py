@@ -339,3 +339,61 @@ def test_graph_replay_matches_eager_cycles():
     for r in range(3):
         n = runs[1][2][r]
         assert torch.equal(runs[1][1][r, :n + 1], Gs[r][:n + 1])
+
+
+def test_full_size_batch_matches_single_request_path():
+    """BASELINE.json's full shapes (Qwen3-8B-DFlash-b16 draft: H 4096, 5 layers, 32/8 heads,
+    FFN 12288, 5 taps of 4096, vocabulary 151936; Qwen3-8B-shaped target cut to 6 layers): four
+    ragged requests through the batched launches — K parts 2 / 6 / 10, slabs, tickets, the
+    launch-boundary residual reduce — against four single-request sessions over two cycles:
+    same committed ids and tau, draft ids agreeing where the margins allow, taps and the K/V
+    rows both paths appended within the bf16 tolerance of DESIGN.md §2."""
+    from dflash_amd import DFlashConfig, DFlashDraftModel, NativeTarget
+    from dflash_amd.batch import BatchedDecoder
+    from dflash_amd.config import QWEN3_8B_DRAFT, QWEN3_8B_TARGET
+    from dflash_amd.generate import DecodeSession
+    from dflash_amd.synthetic import impose_greedy_walk, make_hf_qwen3
+    L = 6
+    cfg = DFlashConfig(**{**QWEN3_8B_DRAFT, "num_target_layers": L, "target_layer_ids": [0, 1, 2, 3, 4]})
+    m = DFlashDraftModel(cfg, device=dev())
+    g = torch.Generator(device=dev()).manual_seed(0)
+    m.load_state_dict({k: (torch.randn(s, generator=g, device=dev(), dtype=torch.float32) * 0.02).to(BF16)
+                       if len(s) == 2 else (1 + 0.1 * torch.randn(s, generator=g, device=dev())).to(BF16)
+                       for k, s in cfg.state_dict_shapes().items()})
+    torch.manual_seed(0)
+    hf = make_hf_qwen3({**QWEN3_8B_TARGET, "num_layers": L}, dev())
+    impose_greedy_walk(hf, seed=9)
+    nt = NativeTarget(hf)
+    lens = (70, 33, 129, 48)
+    prompts = [torch.randint(0, 151000, (1, P), generator=torch.Generator().manual_seed(21 + i)).to(dev())
+               for i, P in enumerate(lens)]
+    dec = BatchedDecoder(m, nt, 4, max_rows=256, out_len=256, mask_token_id=cfg.mask_token_id)
+    sess = []
+    for r, p in enumerate(prompts):
+        dec.admit(r, p)
+        s = DecodeSession(m, nt, p, mask_token_id=cfg.mask_token_id, max_new_tokens=64, max_block_size=16,
+                          stop_token_ids=None, temperature=0.0)
+        s.prefill()
+        sess.append(s)
+    agree = []
+    for cyc in range(2):
+        dec.draft()
+        blocks = dec.block.clone()
+        dec.verify()
+        taps = dec.d["taps"].clone()
+        res = dec.accept()
+        for r, s in enumerate(sess):
+            start = s.start
+            out = s.cycle(16)
+            assert out.tau == res[r][0], (cyc, r)
+            assert torch.equal(s.output_ids[0, :s.start + 1], dec.output_ids[r, :s.start + 1])
+            agree.append(float((s.block[0] == blocks[r]).float().mean()))
+            got, want = taps[r, :out.tau].float(), s.target_hidden[0].float()
+            d = (got - want).abs()
+            assert d.max() <= 4e-2 * want.abs().max() and d.mean() <= 4e-3 * want.abs().max(), (cyc, r)
+            for a, b in ((dec.dk[r, 4][:, :start], s.dcache.k[4][:, :start]), (dec.dv[r, 0][:, :start], s.dcache.v[0][:, :start]),
+                         (dec.tk[r, L - 1][:, :s.start], s.tcache.k[L - 1][:, :s.start])):
+                dd = (a.float() - b.float()).abs()
+                assert dd.max() <= 6e-2 * b.float().abs().max() and dd.mean() <= 4e-3 * b.float().abs().max(), (cyc, r)
+    # random-weight draft logits are near-tied (margins ~ bf16 ulp): most, not all, tokens agree
+    assert sum(agree) / len(agree) >= 0.7, agree
