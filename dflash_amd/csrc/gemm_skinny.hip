@@ -65,10 +65,16 @@ __device__ unsigned long long g_gstamps[8];
 #define GSTAMP(i)
 #endif
 
-template <int MT, bool CHUNKED, int EPI>
-__global__ __launch_bounds__(1024) void k_gemm(GemmArgs a) {
+// The GEMM of one launch as a device function, so that a cooperative multi-stage kernel can run
+// several of them back to back (k_mlp_fused below).  PRE: the weight fragments of the FIRST item
+// (tile blockIdx.x, chunk 0) were already requested by the caller into `pre` — across a grid
+// barrier, so that HBM keeps streaming while the workgroups meet.
+constexpr int gemm_fr(int MT, bool CHUNKED) { return CHUNKED ? 4 : (MT == 1 ? 8 : 4); }
+
+template <int MT, bool CHUNKED, int EPI, bool PRE = false>
+__device__ __forceinline__ void gemm_body(const GemmArgs &a, const bf16x8 *pre) {
   GSTAMP(0);
-  constexpr int FR = CHUNKED ? 4 : (MT == 1 ? 8 : 4);
+  constexpr int FR = gemm_fr(MT, CHUNKED);
   // red[buf][wave][mt][256]: lane l owns floats 4l..4l+3 (its MFMA D regs)
   __shared__ float red[2][16][MT][256];
 
@@ -141,10 +147,10 @@ __global__ __launch_bounds__(1024) void k_gemm(GemmArgs a) {
 #pragma unroll
         for (int f = 0; f < FR; ++f) wv[mt][f] = raw[mt][f] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) issue_x<FR>(a.src[mt], ks, l, nv[mt], raw[mt], wv[mt]);
+      for (int mt = 0; mt < MT; ++mt) issue_x<FR, false>(a.src[mt], ks, l, nv[mt], raw[mt], wv[mt]);  // no mode 2 here
       load_ksteps<FR>(wr, a.wp + ((size_t)t * a.KS + ks0) * 64, nf_of(c), l);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) finish_x<FR>(a.src[mt], take, l, nv[mt], 1.f, raw[mt], wv[mt], xb[mt]);
+      for (int mt = 0; mt < MT; ++mt) finish_x<FR, false>(a.src[mt], take, l, nv[mt], 1.f, raw[mt], wv[mt], xb[mt]);
     }
   };
 
@@ -268,7 +274,12 @@ __global__ __launch_bounds__(1024) void k_gemm(GemmArgs a) {
       for (int f = 0; f < FR; ++f) wv[mt][f] = raw[mt][f] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) issue_x<FR>(a.src[mt], ks, l, nv[mt], raw[mt], wv[mt]);
-    if (nitems > 0) load_item(wA, xA, tile_of(0), 0);  // the first weights, behind the activations
+    if (PRE) {
+#pragma unroll
+      for (int f = 0; f < FR; ++f) wA[f] = pre[f];
+    } else if (nitems > 0) {
+      load_item(wA, xA, tile_of(0), 0);  // the first weights, behind the activations
+    }
     GSTAMP(1);
     if (any_norm) {  // uniform over the workgroup: the modes are kernel arguments
 #pragma unroll
@@ -313,7 +324,28 @@ __global__ __launch_bounds__(1024) void k_gemm(GemmArgs a) {
       arg_rows = a.nrows;
       if (a.dyn && a.nrows_word >= 0) arg_rows = a.dyn[a.nrows_word] - a.row0;
     }
-    if (nitems > 0) load_item(wA, xA, tile_of(0), 0);
+    if (PRE) {  // weights of (tile 0, chunk 0) are in flight already: only the activations remain
+      const int ks0 = ks0_of(0);
+      int ks[FR];
+      bool take[FR];
+#pragma unroll
+      for (int f = 0; f < FR; ++f) {
+        take[f] = ks0 + f < a.KS;
+        ks[f] = take[f] ? ks0 + f : a.KS - 1;
+        wA[f] = pre[f];
+      }
+      bf16x8 raw[MT][FR], wv[MT][FR];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int f = 0; f < FR; ++f) wv[mt][f] = raw[mt][f] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) issue_x<FR, false>(a.src[mt], ks, l, nv[mt], raw[mt], wv[mt]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) finish_x<FR, false>(a.src[mt], take, l, nv[mt], 1.f, raw[mt], wv[mt], xA[mt]);
+    } else if (nitems > 0) {
+      load_item(wA, xA, tile_of(0), 0);
+    }
     GSTAMP(1);
     GSTAMP(2);
   }
@@ -367,6 +399,74 @@ __global__ __launch_bounds__(1024) void k_gemm(GemmArgs a) {
     }
   }
 }
+
+template <int MT, bool CHUNKED, int EPI>
+__global__ __launch_bounds__(1024) void k_gemm(GemmArgs a) {
+  gemm_body<MT, CHUNKED, EPI, false>(a, nullptr);
+}
+
+#ifdef DFL_EXPERIMENTAL_MLP  // built by scripts/probes/bench_mlp_fused.py only, never into the product library
+// ---- EXPERIMENT: two GEMM stages in one cooperative
+// launch — gate/up (SiLU epilogue) -> grid barrier -> down (residual epilogue) — with the second
+// stage's first weights requested BEFORE the barrier, so that HBM streams while the workgroups
+// meet.  One workgroup per CU (cooperative launch: all resident or the launch fails), a
+// hierarchical arrival counter (per-XCD slot = workgroup id % 8, then global), BOUNDED spin: a
+// workgroup that waits > 2 ms sets *fail and goes on (wrong numbers, never a hang).
+struct MlpArgs {
+  GemmArgs gu, down;
+  unsigned *bar;   // [1 + 8] counters, 128 B apart; monotonic: `epoch` = launches so far incl. this one
+  unsigned epoch;
+  int *fail;
+};
+
+__global__ __launch_bounds__(1024) void k_mlp_fused(MlpArgs m) {
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = tid & 63;
+  gemm_body<1, false, EPI_SILU, false>(m.gu, nullptr);
+
+  // ---- publish this workgroup's act columns: drain, then ONE agent-scope release
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  // ---- request the first item of the down stage (tile blockIdx.x, chunk 0): waves 1..15 now,
+  // wave 0 after the barrier (its atomics and polls would queue behind its own loads: vmcnt is
+  // in order)
+  constexpr int FR = gemm_fr(1, true);
+  const GemmArgs &d = m.down;
+  const int ks0 = (0 * 16 + w) * d.nfr;  // chunk 0 of a single-K-part grid
+  int nf = d.KS - ks0;
+  nf = nf < 0 ? 0 : (nf > d.nfr ? d.nfr : nf);
+  const bool has_tile = (int)blockIdx.x < d.ntiles;
+  bf16x8 pre[FR];
+#pragma unroll
+  for (int f = 0; f < FR; ++f) pre[f] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+  if (w != 0 && has_tile) load_ksteps<FR>(pre, d.wp + ((size_t)blockIdx.x * d.KS + ks0) * 64, nf, l);
+  if (tid == 0) {
+    const unsigned nwg = gridDim.x, x = blockIdx.x & 7, per = (nwg + 7 - x) / 8;
+    unsigned *cx = m.bar + 32 * (1 + x), *cg = m.bar;
+    const unsigned tk = __hip_atomic_fetch_add(cx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tk == m.epoch * per - 1) __hip_atomic_fetch_add(cg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned want = m.epoch * (nwg < 8 ? nwg : 8);
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(cg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+      __builtin_amdgcn_s_sleep(1);
+      if (wall_clock64() - t0 > 200000ull) {
+        *m.fail = 1;
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // this CU's L1 may hold stale act lines
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  if (w == 0 && has_tile) load_ksteps<FR>(pre, d.wp + ((size_t)blockIdx.x * d.KS + ks0) * 64, nf, l);
+  __builtin_amdgcn_s_barrier();  // raw: no vmcnt wait, the requested weights stay in flight
+  gemm_body<1, true, EPI_RESID, true>(m.down, pre);
+}
+#endif  // DFL_EXPERIMENTAL_MLP
 
 // Cross-workgroup finish of the fused argmax: one wave per row.  margin_out (optional):
 // top-1 minus top-2 logit of the row — the reference's only confidence statistic
@@ -569,6 +669,64 @@ extern "C" int dfl_gemm_argmax(const void *wp, const dfl_rows *x, int V, int K, 
   DFL_CHECK_LAUNCH("dfl_gemm_argmax");
   return DFL_OK;
 }
+
+#ifdef DFL_EXPERIMENTAL_MLP
+/* EXPERIMENT (scripts/probes/bench_mlp_fused.py): dfl_gemm_silu_mul + dfl_gemm_resid(add_residual) of one MLP as
+ * ONE launch, see k_mlp_fused.  bar_ws: 4096 zeroed bytes; epoch 1, 2, 3, ... per launch (top bit: plain instead of
+ * cooperative launch); the int at bar_ws + 2048 becomes 1 if a workgroup gave up waiting. */
+extern "C" int dfl_mlp_fused(const void *wp_gateup, const dfl_rows *x, int I, int K, void *act_frag, const void *wp_down,
+                             int N, void *h_io, int64_t ldh, float *ss_out, const int32_t *dyn, void *bar_ws,
+                             unsigned epoch, void *stream) {
+  DFL_REQUIRE(wp_gateup && act_frag && wp_down && h_io && bar_ws, "dfl_mlp_fused: null pointer");
+  DFL_REQUIRE(I > 0 && K > 0 && I % 32 == 0 && K % 32 == 0 && N % 16 == 0 && K / 32 <= 128 && I / 32 > 128,
+              "dfl_mlp_fused: shapes outside the experiment (need K <= 4096 < I)");
+  MlpArgs m{};
+  if (!fill_src(m.gu.src[0], x, K, "dfl_mlp_fused")) return DFL_EINVAL;
+  m.gu.wp = (const bf16x8 *)wp_gateup;
+  m.gu.dyn = dyn;
+  m.gu.KS = K / 32;
+  m.gu.ntiles = 2 * (I / 16);
+  m.gu.nfr = (m.gu.KS + 15) / 16;
+  m.gu.nch = 1;
+  m.gu.act = (bf16_t *)act_frag;
+  dfl_rows actsrc{};
+  actsrc.frag = act_frag;
+  actsrc.valid_word = -1;
+  actsrc.mode = 0;
+  if (!fill_src(m.down.src[0], &actsrc, I, "dfl_mlp_fused")) return DFL_EINVAL;
+  m.down.wp = (const bf16x8 *)wp_down;
+  m.down.dyn = dyn;
+  m.down.KS = I / 32;
+  m.down.ntiles = N / 16;
+  m.down.nfr = 4;
+  m.down.nch = (m.down.KS + 63) / 64;
+  m.down.h_io = (bf16_t *)h_io;
+  m.down.ldh = ldh;
+  m.down.add_resid = 1;
+  m.down.ss_out = ss_out;
+  const int g1 = grid_x_for(I / 16), g2 = grid_x_for(m.down.ntiles);
+  DFL_REQUIRE(g1 == g2, "dfl_mlp_fused: the two stages want different grids (%d vs %d)", g1, g2);
+  m.bar = (unsigned *)bar_ws;
+  m.epoch = epoch;
+  m.fail = (int *)((char *)bar_ws + 2048);
+  // epoch's top bit selects a PLAIN launch (experiment: the cooperative launch path itself costs
+  // ~25 us here); residency of all 256 workgroups is then an assumption (one per CU, idle GPU),
+  // backed only by the bounded spin
+  if (epoch & 0x80000000u) {
+    m.epoch = epoch & 0x7fffffffu;
+    hipLaunchKernelGGL(k_mlp_fused, dim3(g1), dim3(1024), 0, (hipStream_t)stream, m);
+    DFL_CHECK_LAUNCH("dfl_mlp_fused");
+    return DFL_OK;
+  }
+  void *args[] = {&m};
+  const hipError_t e = hipLaunchCooperativeKernel((const void *)k_mlp_fused, dim3(g1), dim3(1024), args, 0, (hipStream_t)stream);
+  if (e != hipSuccess) {
+    dfl_set_error("dfl_mlp_fused: cooperative launch failed: %s", hipGetErrorString(e));
+    return DFL_ELAUNCH;
+  }
+  return DFL_OK;
+}
+#endif  // DFL_EXPERIMENTAL_MLP
 
 extern "C" int dfl_gemm_resid(const void *wp, const dfl_rows *x, int N, int K, void *h_io, int64_t ldh,
                               int add_residual, void *tap, int64_t ldtap, float *ss_out, const int32_t *dyn,
