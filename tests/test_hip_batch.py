@@ -397,3 +397,46 @@ def test_full_size_batch_matches_single_request_path():
                 assert dd.max() <= 6e-2 * b.float().abs().max() and dd.mean() <= 4e-3 * b.float().abs().max(), (cyc, r)
     # random-weight draft logits are near-tied (margins ~ bf16 ulp): most, not all, tokens agree
     assert sum(agree) / len(agree) >= 0.7, agree
+
+
+def test_batch_with_llama_style_target():
+    """BASELINE config 4's target family in the batched loop: a Llama-layout target (no per-head
+    q/k norm, "llama3" RoPE frequency scaling active at these positions) behind NativeTarget;
+    every request equals its single-request run."""
+    tf = pytest.importorskip("transformers")
+    from dflash_amd import DFlashDraftModel, NativeTarget, dflash_generate
+    from dflash_amd.batch import dflash_generate_batch
+    from dflash_amd.synthetic import greedy_walk, impose_greedy_walk
+    cfg = H.tiny_cfg(num_target_layers=4)
+    m = DFlashDraftModel(cfg, device=dev())
+    m.load_state_dict(H.draft_weights(cfg, seed=3, dtype=BF16))
+    lc = tf.LlamaConfig(vocab_size=2048, hidden_size=512, intermediate_size=1024, num_hidden_layers=4,
+                        num_attention_heads=4, num_key_value_heads=2, head_dim=128, rms_norm_eps=1e-5,
+                        max_position_embeddings=4096, tie_word_embeddings=False, attention_bias=False, mlp_bias=False,
+                        rope_parameters={"rope_type": "llama3", "rope_theta": 500000.0, "factor": 8.0,
+                                         "low_freq_factor": 1.0, "high_freq_factor": 4.0,
+                                         "original_max_position_embeddings": 32})
+    lc._attn_implementation = "sdpa"
+    torch.manual_seed(3)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(BF16)
+    try:
+        with torch.device(dev()):
+            hf = tf.LlamaForCausalLM(lc).eval()
+    finally:
+        torch.set_default_dtype(prev)
+    perm = impose_greedy_walk(hf, seed=6)
+    nt = NativeTarget(hf)
+    lens, n_new = (26, 41, 9), 48
+    prompts = [torch.randint(0, 2000, (1, P), generator=torch.Generator().manual_seed(80 + i)).to(dev())
+               for i, P in enumerate(lens)]
+    Gs = [greedy_walk(perm, p, n_new + 40).to(dev()) for p in prompts]
+    plans = [H.make_plan(64, 16, 50 + i) for i in range(3)]
+    hooks = [_hook_for(Gs[i], plans[i]) for i in range(3)]
+    singles = [dflash_generate(m, nt, prompts[i], cfg.mask_token_id, n_new, 16, None, 0.0, draft_token_hook=hooks[i])
+               for i in range(3)]
+    outs = dflash_generate_batch(m, nt, prompts, cfg.mask_token_id, n_new, 16, None, 0.0,
+                                 draft_token_hook=lambda i, blk, s, c: hooks[i](blk[:, :min(16, lens[i] + n_new - s)], s, c))
+    for i in range(3):
+        assert outs[i].output_ids[0].tolist() == singles[i].output_ids[0].tolist() == Gs[i][:lens[i] + n_new].tolist(), i
+        assert outs[i].acceptance_lengths == singles[i].acceptance_lengths
