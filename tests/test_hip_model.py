@@ -382,6 +382,46 @@ def test_native_target_llama_style(rope):
         assert d.max() <= 6e-2 * want.float().abs().max() and d.mean() <= 4e-3 * want.float().abs().max()
 
 
+def test_qwen3_4b_geometry_matches_oracle():
+    """Qwen3-4B's geometry (BASELINE configs[0]): q_dim = heads x 128 = 1024 != hidden 640 here
+    (4096 != 2560 there), FFN not a multiple of 1024, hidden % 512 != 0 — the o_proj / qkv
+    shapes no other fixture has.  Three draft cycles with cache against the CPU oracle on the same
+    seeded weights, then an end-to-end scripted run against the oracle's loop."""
+    from oracle import dflash_oracle as O
+    from dflash_amd import DFlashDraftModel
+    from dflash_amd.config import DFlashConfig
+    cfg = DFlashConfig(hidden_size=640, num_hidden_layers=2, num_attention_heads=8, num_key_value_heads=2, head_dim=128,
+                       intermediate_size=2432, vocab_size=3072, num_target_layers=6, block_size=16, rope_theta=1e6,
+                       mask_token_id=3071)
+    assert cfg.q_dim != cfg.hidden_size
+    w = H.draft_weights(cfg, seed=21, dtype=BF16)
+    m = DFlashDraftModel(cfg, device=dev())
+    m.load_state_dict(w)
+    oc = H.oracle_cfg(cfg, "sdpa")
+    g = torch.Generator().manual_seed(9)
+    ocache = O.ListKVCache()
+    cache = m.new_cache(256)
+    start = 37
+    for c, (ctx, bs, tau_next) in enumerate(((37, 16, 5), (5, 16, 16), (16, 12, 3))):
+        th = (torch.randn(1, ctx, cfg.fc_in, generator=g) * 1.5).to(BF16)
+        ne = (torch.randn(1, bs, cfg.hidden_size, generator=g) * 0.05).to(BF16)
+        pos = torch.arange(ocache.get_seq_length(), start + bs)[None]
+        ref = O.draft_forward(w, oc, position_ids=pos, noise_embedding=ne, target_hidden=th, cache=ocache)
+        ocache.crop(start)
+        got = m(target_hidden=th.to(dev()), noise_embedding=ne.to(dev()), position_ids=pos.to(dev()),
+                past_key_values=cache, use_cache=True, is_causal=False)
+        cache.crop(start)
+        d = (got.float().cpu() - ref.float()).abs()
+        scale = ref.float().abs().max()
+        assert d.max() <= 4e-2 * scale and d.mean() <= 4e-3 * scale, (c, float(d.max()), float(scale))
+        start += tau_next
+    n = cache.get_seq_length()
+    for li in range(cfg.num_hidden_layers):
+        for got, want in ((cache.k[li][:, :n], ocache.k[li][0]), (cache.v[li][:, :n], ocache.v[li][0])):
+            dd = (got.float().cpu() - want.float()).abs()
+            assert dd.max() <= 6e-2 * want.float().abs().max() and dd.mean() <= 4e-3 * want.float().abs().max()
+
+
 def test_full_size_draft_cycle_matches_oracle():
     """BASELINE.json's full shapes (Qwen3-8B-DFlash-b16: H 4096, 5 layers, 32/8 heads,
     FFN 12288, 5 taps): a prompt-context cycle and a steady cycle of the draft forward
