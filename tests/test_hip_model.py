@@ -386,7 +386,7 @@ def test_qwen3_4b_geometry_matches_oracle():
     """Qwen3-4B's geometry (BASELINE configs[0]): q_dim = heads x 128 = 1024 != hidden 640 here
     (4096 != 2560 there), FFN not a multiple of 1024, hidden % 512 != 0 — the o_proj / qkv
     shapes no other fixture has.  Three draft cycles with cache against the CPU oracle on the same
-    seeded weights, then an end-to-end scripted run against the oracle's loop."""
+    seeded weights; then the native target verify at the same geometry against the HF forward."""
     from oracle import dflash_oracle as O
     from dflash_amd import DFlashDraftModel
     from dflash_amd.config import DFlashConfig
@@ -420,6 +420,32 @@ def test_qwen3_4b_geometry_matches_oracle():
         for got, want in ((cache.k[li][:, :n], ocache.k[li][0]), (cache.v[li][:, :n], ocache.v[li][0])):
             dd = (got.float().cpu() - want.float()).abs()
             assert dd.max() <= 6e-2 * want.float().abs().max() and dd.mean() <= 4e-3 * want.float().abs().max()
+
+
+    # ---- target side: a 4-layer HF Qwen3 of the same geometry through NativeTarget.verify
+    from transformers import DynamicCache
+    from dflash_amd import NativeTarget
+    from dflash_amd.synthetic import make_hf_qwen3
+    torch.manual_seed(13)
+    hf = make_hf_qwen3(dict(vocab_size=3072, hidden_size=640, num_layers=4, num_heads=8, num_kv_heads=2, head_dim=128,
+                            intermediate_size=2432, rope_theta=1e6), dev())
+    nt = NativeTarget(hf)
+    prompt = torch.randint(0, 3000, (1, 50), generator=g).to(dev())
+    block = torch.randint(0, 3000, (1, 16), generator=g).to(dev())
+    tc = nt.new_cache(128)
+    nt.prefill(prompt, tc)
+    logits = torch.zeros(16, 3072, dtype=BF16, device=dev())
+    post, taps = nt.verify(block[0], 50, tc, tap_layers=[0, 2], logits_out=logits)
+    rc = DynamicCache()
+    hf(prompt, past_key_values=rc, use_cache=True)
+    refo = hf(block, position_ids=torch.arange(50, 66, device=dev())[None], past_key_values=rc, use_cache=True,
+              output_hidden_states=True)
+    rl = refo.logits[0].float()
+    assert (logits.float() - rl).abs().max() <= 4e-2 * rl.abs().max()
+    for j, li in enumerate((0, 2)):
+        r = refo.hidden_states[li + 1][0].float()
+        dd = (taps[:, j * 640:(j + 1) * 640].float() - r).abs()
+        assert dd.max() <= 4e-2 * r.abs().max() and dd.mean() <= 4e-3 * r.abs().max()
 
 
 def test_full_size_draft_cycle_matches_oracle():
