@@ -56,27 +56,39 @@ def make_hf_target(dev, layers=36):
     return m, impose_greedy_walk(m, seed=1234)   # large-margin greedy rule, see module docstring
 
 
-def tau_plan(n, bs, seed, mean_tau=7.3, block=20):
-    """k_c = number of agreeing draft tokens per cycle; tau = k + 1 = 1 + min(Geom(p), bs-1)
-    with p solving E[tau] = mean_tau.  Drawn in blocks of `block` cycles, each block
-    re-drawn (seeded) until its taus sum to round(block * mean_tau): any window the driver
-    times has the published mean acceptance length to within a fraction of a block."""
+def tau_plan(n_pre, steps, bs, seed, mean_tau=7.3, extra=8):
+    """k_c = number of agreeing draft tokens per cycle; tau = k + 1 = 1 + min(Geom(p), bs-1) with
+    p solving E[tau] = mean_tau.  The first n_pre cycles (cycle 0 + warmup) and `extra` spare
+    ones are free draws; the `steps` TIMED cycles are one seeded draw conditioned on their taus
+    summing to round(steps * mean_tau), so the timed window has the published mean acceptance
+    length whatever --steps the driver picks (a free window of 48 cycles is off by +-1-2 %)."""
     lo, hi = 0.0, 1.0
     for _ in range(60):
         p = 0.5 * (lo + hi)
         m = 1.0 + sum(p ** j for j in range(1, bs))
         lo, hi = (p, hi) if m < mean_tau else (lo, p)
     g = torch.Generator().manual_seed(seed)
-    want = round(block * mean_tau)
-    out = []
-    while len(out) < n:
-        for _ in range(10000):
-            u = torch.rand(block, bs - 1, generator=g)
-            k = (u < p).long().cumprod(dim=1).sum(dim=1)
-            if int(k.sum()) + block == want:
-                break
-        out += k.tolist()
-    return out[:n]
+
+    def draw(n):
+        u = torch.rand(n, bs - 1, generator=g)
+        return (u < p).long().cumprod(dim=1).sum(dim=1)
+
+    pre = draw(n_pre).tolist()
+    want = round(steps * mean_tau)
+    k = draw(steps)
+    for _ in range(20000):
+        if int(k.sum()) + steps == want:
+            break
+        k = draw(steps)
+    else:  # never seen; nudge single cycles so the sum still matches
+        k = k.clone()
+        i = 0
+        while int(k.sum()) + steps != want:
+            d = 1 if int(k.sum()) + steps < want else -1
+            if 0 <= int(k[i % steps]) + d <= bs - 1:
+                k[i % steps] += d
+            i += 1
+    return pre + k.tolist() + draw(extra).tolist()
 
 
 def gpu_leg(args, rank, world, dev):
@@ -108,7 +120,7 @@ def gpu_leg(args, rank, world, dev):
     bs, P = 16, args.prefix
     prompt = torch.randint(0, 151000, (1, P), generator=torch.Generator().manual_seed(1 + rank)).to(dev)
     ncyc = args.warmup + args.steps + 1
-    plan = tau_plan(ncyc + 8, bs, seed=100 + rank)
+    plan = tau_plan(1 + args.warmup, args.steps, bs, seed=100 + rank)
     need = sum(k + 1 for k in plan[:ncyc]) + 2 * bs
     mask_id = cfg.mask_token_id
 
@@ -190,7 +202,7 @@ def batched_leg(args, rank, dev, draft, target, perm, cfg):
     from dflash_amd.synthetic import greedy_walk
     R, bs, P = args.requests_per_gpu, 16, args.prefix
     ncyc = args.warmup + args.steps + 1
-    plans = [tau_plan(ncyc + 8, bs, seed=100 + rank * 16 + r) for r in range(R)]
+    plans = [tau_plan(1 + args.warmup, args.steps, bs, seed=100 + rank * 16 + r) for r in range(R)]
     need = max(sum(k + 1 for k in pl[:ncyc]) for pl in plans) + 2 * bs
     prompts = [torch.randint(0, 151000, (1, P), generator=torch.Generator().manual_seed(1 + rank * 16 + r)).to(dev)
                for r in range(R)]
@@ -382,7 +394,7 @@ def main():
             "config": {"workload": "Qwen3-8B-shaped target (" + ("HF/PyTorch-ROCm verify" if args.hf_verify else
                                    "HF prefill, NativeTarget verify on the kernels") + ") + DFlash-b16 5-layer draft, "
                                    f"block=16, temp=0, batch={args.requests_per_gpu} per GPU, prefix={args.prefix}, random-init weights, "
-                                   "scripted acceptance (seeded truncated-geometric, mean tau 7.3 per 20-cycle block)",
+                                   "scripted acceptance (seeded truncated-geometric, mean tau 7.3 over the timed cycles)",
                        "target_layers": args.target_layers, "requests": world * args.requests_per_gpu,
                        "target_verify": "hf" if args.hf_verify else "native", "parallelism": f"dp{world}"},
             "mean_acceptance_length": res["mean_tau"], "raw_tau1_value": res["raw_tau1_value"],
