@@ -511,3 +511,39 @@ def test_long_prefix_many_key_splits():
     ref = hf(block, position_ids=torch.arange(P, P + 16, device=dev())[None], past_key_values=rc, use_cache=True)
     rl = ref.logits[0].float()
     assert (logits.float() - rl).abs().max() <= 4e-2 * rl.abs().max()
+
+
+def test_harness_options_on_native_target():
+    """The harness-level options of benchmark.py / benchmark_dynamic_schedule.py on the native
+    verify: per-cycle profile (benchmark.py:99-240), draft_steps = 2 (:112-142), the block-size
+    scheduler loop with T > 0 draft sampling (benchmark_dynamic_schedule.py:321-379) and the
+    bs = 1 baseline — all must commit the target's own greedy walk."""
+    from dflash_amd import EWMAPerformanceScheduler, NativeTarget, dflash_generate, dflash_generate_policy
+    from dflash_amd.synthetic import greedy_walk, impose_greedy_walk
+    cfg = H.tiny_cfg()
+    m = make_model(cfg)
+    hf = _tiny_hf()
+    perm = impose_greedy_walk(hf, seed=5)
+    nt = NativeTarget(hf)
+    prompt = torch.randint(0, 2000, (1, 27), generator=torch.Generator().manual_seed(14)).to(dev())
+    n_new = 50
+    G = greedy_walk(perm, prompt, n_new + 40).to(dev())
+    want = G[:27 + n_new].tolist()
+    r = dflash_generate(m, nt, prompt, cfg.mask_token_id, n_new, 16, None, 0.0, collect_profile=True)
+    assert r.output_ids[0].tolist() == want
+    ps = r.profile_summary
+    assert ps["profiled_cycles"] == len(r.acceptance_lengths) and ps["draft_decode_s"] > 0 and ps["target_decode_s"] > 0
+    assert abs(ps["draft_share_decode"] + ps["target_share_decode"] - 1.0) < 1e-6
+    r2 = dflash_generate(m, nt, prompt, cfg.mask_token_id, n_new, 16, None, 0.0, draft_steps=2)
+    assert r2.output_ids[0].tolist() == want
+    r1 = dflash_generate(m, nt, prompt, cfg.mask_token_id, n_new, 1, None, 0.0)   # bs = 1: plain target AR
+    assert r1.output_ids[0].tolist() == want and r1.acceptance_lengths == [1] * n_new
+    sched = EWMAPerformanceScheduler(candidates=[8, 12, 16], scheduler_mode="ewma", warmup_cycles=3, ewma_alpha=0.25,
+                                     switch_margin=0.03, required_streak=2, cooldown_cycles=2, probe_interval=5,
+                                     low_accept_threshold=0.2, low_accept_streak=3, adl_rho=0.3, adl_delta=1.0,
+                                     adl_k_min=8, adl_k_max=16, adl_neighborhood=4)
+    torch.manual_seed(0)
+    rp = dflash_generate_policy(model=m, target=nt, input_ids=prompt, mask_token_id=cfg.mask_token_id,
+                                max_new_tokens=n_new, stop_token_ids=None, temperature=0.7, scheduler=sched)
+    assert rp.output_ids[0].tolist() == want          # margin ~70: the T = 0.7 posterior draw is the argmax
+    assert set(rp.used_block_sizes) <= {8, 12, 16} | set(range(1, 17)) and len(rp.cycle_trace) == len(rp.acceptance_lengths)
