@@ -351,6 +351,56 @@ def cpu_leg(args, mean_tau):
                       f"build {build_s:.0f}s untimed"}
 
 
+def launch_ranks(n: int) -> int:
+    """One fresh child process per GPU (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, as torch.distributed.run would),
+    started BEFORE this process makes any GPU call and never by re-exec'ing a process that did.  Rank 0 prints the
+    JSON line; the launcher only forwards exit codes (run_benchmark.sh:120-133 launches torchrun the same way)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env))
+    rc = 0
+    try:
+        for p in procs:
+            code = p.wait()
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                for q in procs:     # one rank failed: the others would wait in a collective for ever
+                    if q.poll() is None:
+                        q.terminate()
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def selftest_cpu(args, rank, world, use_pg):
+    """--selftest-cpu: the N > 1 control flow of main() without kernels (gloo on the host)."""
+    import torch.distributed as dist
+    from dflash_amd import distributed as D
+    if use_pg:
+        dist.init_process_group("gloo")
+        world = dist.get_world_size()
+        dist.barrier()
+    dt, units = D.reduce_timing(0.001 * (rank + 1), float(args.steps))
+    if rank == 0:
+        print(json.dumps({"metric": "accepted_tokens_per_sec", "value": None, "unit": "tokens/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "selftest": "cpu launcher plumbing, no kernels",
+                          "cycles_all_ranks": units, "config": {"parallelism": f"dp{world}",
+                                                                "requests": world * args.requests_per_gpu}}),
+              flush=True)
+    if use_pg:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -369,19 +419,34 @@ def main():
     ap.add_argument("--hf-verify", action="store_true",
                     help="verify through the HF/PyTorch target forward (round-1 configuration) instead of "
                          "dflash_amd.NativeTarget")
+    ap.add_argument("--selftest-cpu", action="store_true",
+                    help="launcher plumbing only (tests/test_distributed_cpu.py): ranks rendezvous over gloo, run no "
+                         "kernels and report value null; never a measurement")
     args = ap.parse_args()
+
+    if "RANK" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N`: this process becomes the launcher and never touches a GPU
+        raise SystemExit(launch_ranks(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python bench.py --gpus N does it itself)")
+    use_pg = "RANK" in os.environ   # launched by torch.distributed.run or by launch_ranks (also with one rank)
+    if args.selftest_cpu:
+        return selftest_cpu(args, rank, world, use_pg)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants cuda:{local} but only {torch.cuda.device_count()} GPUs are visible")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    use_pg = "RANK" in os.environ   # launched by torch.distributed.run (also with one rank: same code path)
     if use_pg:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.distributed.init_process_group("nccl", device_id=dev)  # RCCL; timing scalars only
+        world = torch.distributed.get_world_size()                    # n_gpus = the RCCL world actually seen
 
     res = gpu_leg(args, rank, world, dev)
     cpu = None

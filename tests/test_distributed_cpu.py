@@ -54,3 +54,42 @@ def test_single_process_degrades():
     assert D.size() == 1 and D.rank() == 0 and list(D.shard_indices(5)) == [0, 1, 2, 3, 4]
     assert D.gather("x") == ["x"]
     assert D.reduce_timing(1.5, 3.0) == (1.5, 3.0)
+
+
+def _run_bench(argv, env_extra=None):
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(H.ROOT, "bench.py"), *argv], env=env, capture_output=True,
+                       text=True, timeout=300)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r.returncode, [json.loads(ln) for ln in lines], r.stderr
+
+
+def test_bench_gpus_flag_launches_that_many_ranks():
+    """`python bench.py --gpus 2` (the driver's form, no RANK in the env) must itself start two
+    ranks and report the world size the ranks actually saw — with gloo and no kernels here."""
+    rc, lines, err = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "0", "--selftest-cpu"])
+    assert rc == 0, err
+    assert len(lines) == 1, lines          # rank 0 alone prints
+    assert lines[0]["n_gpus"] == 2 and lines[0]["config"]["parallelism"] == "dp2"
+    assert lines[0]["cycles_all_ranks"] == 6.0   # summed over both ranks
+    assert lines[0]["value"] is None             # a selftest never reports a measurement
+
+
+def test_bench_rejects_a_world_that_differs_from_gpus():
+    rc, lines, err = _run_bench(["--gpus", "2", "--selftest-cpu"],
+                                {"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
+                                 "MASTER_PORT": str(_free_port())})
+    assert rc != 0 and not lines and "WORLD_SIZE=1" in err
+
+
+def test_bench_launcher_forwards_a_failing_rank():
+    # no GPU here: every rank exits non-zero before any rendezvous, and so must the launcher
+    if torch.cuda.is_available():
+        return
+    rc, lines, err = _run_bench(["--gpus", "2", "--steps", "1"])
+    assert rc != 0 and not lines
