@@ -246,10 +246,19 @@ class BatchedDecoder:
             raise NotImplementedError("tapping the last layer (post-norm state) is not supported")
         nsp = ops.batch_ksplit(H)
         ops.embed_rows_batch(t.embed, self.block, R, tt["h"], H, tt["ss_emb"], self.dyn_t, ops.DYN_BS)
-        pend, ptap = 0, None  # K and tap view of the down_proj whose sums wait in part_h
+        pend, ptap, pdup = 0, None, ()  # K and tap view of the down_proj whose sums wait in part_h
+        slots = {}   # tapped layer -> its slots in the tap rows (build_target_layer_ids repeats layers for
+        for j, l in enumerate(tl):   # shallow targets: model/utils.py:16-25 concatenates the state twice)
+            slots.setdefault(l, []).append(j)
+
+        def spread(dups):   # the other slots of a repeated tap id get the same rows
+            for a, b in dups:
+                taps[:, :, b * H:(b + 1) * H].copy_(taps[:, :, a * H:(a + 1) * H])
+
         for i, lw in enumerate(t.layers):
             ops.norm_frag_batch(tt["h"], R, lw["ln1"], t.eps, tt["xn"], self.dyn_t, ops.DYN_BS,
                                 part=tt["part_h"] if pend else None, N=H, K=pend, tap=ptap)
+            spread(pdup)
             ops.gemm_f32_batch(lw["qkv"], s["xn"], R, t.nqkv, H, tt["part_qkv"], self.dyn_t)
             ops.attn_fused_batch(qkv=tt["part_qkv"], nsplit=nsp, split_stride=MT * 16 * t.nqkv, ld=t.nqkv, q_col=0,
                                  k_col=t.q_dim, v_col=t.q_dim + t.kv_dim, R=R, n_q=t.n_q, n_kv=t.n_kv,
@@ -264,9 +273,12 @@ class BatchedDecoder:
             ops.gemm_f32_batch(lw["down"], s["act"], R, H, t.I, tt["part_h"], self.dyn_t)
             # the layer's output (a tapped layer's hidden rows, model/utils.py:16-25) exists once the
             # next norm launch has added these sums: it writes the tap
-            pend, ptap = t.I, (taps[:, :, tl.index(i) * H:(tl.index(i) + 1) * H] if i in tl else None)
+            sl = slots.get(i, ())
+            pend, ptap = t.I, (taps[:, :, sl[0] * H:(sl[0] + 1) * H] if sl else None)
+            pdup = [(sl[0], b) for b in sl[1:]]
         ops.norm_frag_batch(tt["h"], R, t.norm, t.eps, tt["xn"], self.dyn_t, ops.DYN_BS, part=tt["part_h"], N=H, K=pend,
                             tap=ptap)
+        spread(pdup)
         if self.temperature < 1e-5:
             ops.gemm_argmax_batch(self.lm_wp, s["xn"], R, t.V, H, 0, 16, self.gws, self.post, 0, self.dyn_t,
                                   nrows_dyn_word=ops.DYN_BS)
@@ -341,12 +353,14 @@ class BatchedDecoder:
         return self.accept(launch=False)
 
     @torch.inference_mode()
-    def cycle(self, draft_token_hook: Optional[Callable] = None) -> list:
+    def cycle(self, draft_token_hook: Optional[Callable] = None, after_draft: Optional[Callable] = None) -> list:
         """One decode cycle of every live request.  draft_token_hook(r, block_row, start,
         call): test/bench instrumentation for scripted acceptance, as in DecodeSession."""
         self._mark("draft", 0)
         self.draft()
         self._mark("draft", 1)
+        if after_draft is not None:
+            after_draft()
         if draft_token_hook is not None:
             for r in range(self.R):
                 if self.live[r]:
@@ -386,6 +400,7 @@ def dflash_generate_batch(model: DFlashDraftModel, target: NativeTarget, input_i
         taus = [[] for _ in idx]
         hook = (lambda r, blk, start, call: draft_token_hook(idx[r], blk, start, call)) if draft_token_hook else None
         t1 = cuda_time()
+        clock = [t1]
         first = True
         stop_always = stop_token_ids is not None and mask_token_id in stop_token_ids
         for r in range(len(idx)):   # nothing to generate
@@ -395,10 +410,12 @@ def dflash_generate_batch(model: DFlashDraftModel, target: NativeTarget, input_i
             for r in range(len(idx)):  # tail clamp (benchmark.py:104-105)
                 if dec.live[r]:
                     dec.set_block_size(r, max(1, min(block_size, max_len[r] - dec.start[r])))
-            out = dec.cycle(hook)
-            if first:
+            if first:   # the clock restarts after the first draft, before its verify (benchmark.py:145-147)
                 first = False
-                t1 = cuda_time()   # TPOT excludes cycle 0 (benchmark.py:145-147)
+                out = dec.cycle(hook, after_draft=lambda: clock.__setitem__(0, cuda_time()))
+                t1 = clock[0]
+            else:
+                out = dec.cycle(hook)
             for r, o in enumerate(out):
                 if o is None:
                     continue

@@ -182,7 +182,8 @@ extern "C" int dfl_accept_commit(const int64_t *block_ids, const int64_t *poster
                                  int64_t output_len, int32_t *dyn, const int64_t *stop_ids, int n_stop,
                                  int32_t *result, void *stream) {
   DFL_REQUIRE(block_ids && posterior && output_ids && dyn, "dfl_accept_commit: null pointer");
-  DFL_REQUIRE(bs >= 1 && bs <= 64, "dfl_accept_commit: bs=%d outside 1..64", bs);
+  // lane acc + 1 <= bs writes the bonus token: bs = 64 would need a 65th lane
+  DFL_REQUIRE(bs >= 1 && bs <= 63, "dfl_accept_commit: bs=%d outside 1..63", bs);
   DFL_REQUIRE(n_stop == 0 || stop_ids, "dfl_accept_commit: n_stop>0 without stop_ids");
   hipLaunchKernelGGL(k_accept_commit, dim3(1), dim3(64), 0, (hipStream_t)stream, block_ids, posterior, bs, output_ids,
                      output_len, dyn, stop_ids, n_stop, result);

@@ -26,6 +26,7 @@ from . import ops
 from .utils import extract_context_feature, sample
 
 _TABLES = {}
+MAX_BLOCK = 16  # rows per block the kernels take
 
 
 def cuda_time() -> float:
@@ -81,6 +82,9 @@ class DecodeSession:
             raise RuntimeError("dflash_amd: input_ids must be on the GPU")
         if input_ids.shape[0] != 1:
             raise NotImplementedError("batch = 1 per call, as in the reference; shard requests over ranks")
+        if not 1 <= int(max_block_size) <= MAX_BLOCK:
+            raise ValueError(f"block size {max_block_size}: the gfx950 kernels take blocks of 1..{MAX_BLOCK} rows "
+                             f"(two 16-row tiles); checked here, before the target prefill runs")
         self.model, self.target, self.dev = model, target, dev
         self.input_ids = input_ids
         self.mask_token_id, self.temperature = mask_token_id, temperature
@@ -248,11 +252,18 @@ def run_decode(model, target, input_ids: torch.Tensor, *, mask_token_id: int, ma
         lg = [float(bs)]
 
         def after_draft(blk, lg=lg, bs=bs):
+            nonlocal draft_prefill, decode_start
             # EOS-aware generated length of the policy loop (benchmark_dynamic_schedule.py:344-349)
             if scheduler is not None and s.stop_t is not None:
                 pos = torch.isin(blk[0, 1:], s.stop_t).nonzero(as_tuple=True)[0]
                 if pos.numel() > 0:
                     lg[0] = float(min(int(pos[0].item()) + 1, bs))
+            if draft_prefill:
+                # the TPOT clock restarts right after the FIRST draft call and before that cycle's target
+                # forward (benchmark.py:145-147, benchmark_dynamic_schedule.py:352-354): it drops the
+                # prompt-context projection, not cycle 0's verify
+                draft_prefill = False
+                decode_start = cuda_time()
 
         # hidden states: always in spec_generate / the policy loop, only for bs > 1 in the
         # harness form (benchmark.py:157)
@@ -260,9 +271,6 @@ def run_decode(model, target, input_ids: torch.Tensor, *, mask_token_id: int, ma
         gen_before = s.start - s.n_in
         start_idx = s.start
         r = s.cycle(bs, draft_steps=draft_steps, want_hidden=want_hidden, after_draft=after_draft)
-        if bs > 1 and draft_prefill:
-            draft_prefill = False
-            decode_start = cuda_time()  # TPOT excludes cycle 0's prompt-context projection (benchmark.py:145-147)
         taus.append(r.tau)
         used_bs.append(bs)
         lgens.append(lg[0])

@@ -222,9 +222,14 @@ class NativeTarget:
             ops.gemm_resid(lw["o"], src["attn"], H, self.q_dim, ws["h"], add_residual=True, ss_out=ws["ss_h"],
                            dyn=dyn)
             ops.gemm_silu_mul(lw["gu"], src["ln2"][i], self.I, H, ws["act"], dyn)
-            tap = taps[:, tap_layers.index(i) * H:(tap_layers.index(i) + 1) * H] if i in tap_layers else None
+            # every slot j with tap_layers[j] == i: build_target_layer_ids repeats layers for shallow
+            # targets and the reference concatenates the same state twice (model/utils.py:16-25)
+            sl = [j for j, l in enumerate(tap_layers) if l == i]
+            tap = taps[:, sl[0] * H:(sl[0] + 1) * H] if sl else None
             ops.gemm_resid(lw["down"], src["act"], H, self.I, ws["h"], add_residual=True, ss_out=ws["ss_h"], tap=tap,
                            dyn=dyn)
+            for j in sl[1:]:
+                taps[:, j * H:(j + 1) * H].copy_(tap)
         post = ws["post"]
         if temperature < 1e-5:
             ops.gemm_argmax(self.lm_wp, src["final"], self.V, H, 0, bs, ws["argmax_ws"], post, 0, dyn=dyn,

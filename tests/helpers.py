@@ -166,3 +166,58 @@ class ScriptedTarget:
                 block_ids[0, j + 1] = tok
             elif j == k and int(block_ids[0, j + 1]) == tok:
                 block_ids[0, j + 1] = (tok + 1) % self.base.cfg.vocab_size
+
+
+# ---- tolerance checks that also RECORD what was achieved -----------------------------------
+# Every bf16 tolerance test goes through `assert_close`: it asserts max-abs and mean-abs error
+# relative to the reference's scale, prints the achieved values (pytest -rP / -s shows them) and
+# appends them to gpurun_out/parity_errors.jsonl on the GPU box, so the stated tolerance can be
+# read against the measured headroom (VERDICT r1 weak #1d).
+MAX_REL, MEAN_REL = 4e-2, 4e-3      # of the reference tensor's max-abs; DESIGN.md §2
+KV_MAX_REL = 6e-2                   # cached K rows: one more RoPE rounding chain on top
+
+
+def _log_parity(rec: dict) -> None:
+    import json
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_errors.jsonl"), "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    except OSError:
+        pass
+
+
+def assert_close(name: str, got: torch.Tensor, ref: torch.Tensor, max_rel: float = MAX_REL,
+                 mean_rel: float = MEAN_REL) -> tuple:
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    assert got.shape == ref.shape, (name, tuple(got.shape), tuple(ref.shape))
+    scale = float(ref.abs().max())
+    d = (got - ref).abs()
+    mx, mn = float(d.max()) / max(scale, 1e-30), float(d.mean()) / max(scale, 1e-30)
+    rec = {"test": os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0], "what": name, "scale": scale,
+           "max_rel": mx, "mean_rel": mn, "tol_max": max_rel, "tol_mean": mean_rel}
+    print(f"[parity] {name}: max {mx:.3e} (tol {max_rel:.0e})  mean {mn:.3e} (tol {mean_rel:.0e})  scale {scale:.3g}")
+    _log_parity(rec)
+    assert mx <= max_rel, f"{name}: max-abs error {mx:.3e} of scale exceeds {max_rel:.1e}"
+    assert mn <= mean_rel, f"{name}: mean-abs error {mn:.3e} of scale exceeds {mean_rel:.1e}"
+    return mx, mn
+
+
+def assert_ids_match_where_safe(name: str, got_ids: torch.Tensor, ref_logits: torch.Tensor, margin_rel: float = 6e-2,
+                                min_safe: int = 1, min_agree: float = 0.0) -> None:
+    """argmax ids must equal the reference's wherever its top-2 margin exceeds margin_rel x scale
+    (near-ties may flip under bf16); the screened subset must not be empty."""
+    ref_logits = ref_logits.detach().float().cpu()
+    got_ids = got_ids.detach().cpu()
+    scale = float(ref_logits.abs().max())
+    top2 = ref_logits.topk(2, dim=-1).values
+    safe = (top2[:, 0] - top2[:, 1]) > margin_rel * scale
+    ref_ids = ref_logits.argmax(-1)
+    agree = float((got_ids == ref_ids).float().mean())
+    print(f"[parity] {name}: {int(safe.sum())}/{safe.numel()} rows margin-screened, overall id agreement {agree:.3f}")
+    _log_parity({"test": os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0], "what": name + " ids",
+                 "safe_rows": int(safe.sum()), "rows": int(safe.numel()), "agree": agree})
+    assert int(safe.sum()) >= min_safe, f"{name}: only {int(safe.sum())} margin-screened rows (need >= {min_safe})"
+    assert torch.equal(got_ids[safe], ref_ids[safe]), f"{name}: ids differ on margin-screened rows"
+    assert agree >= min_agree, f"{name}: id agreement {agree:.3f} < {min_agree}"

@@ -5,6 +5,8 @@ import os
 import re
 from types import SimpleNamespace
 
+import pytest
+
 import helpers as H
 from dflash_amd import harness
 
@@ -54,3 +56,49 @@ def test_jsonl_rows(tmp_path):
                    "block_size": 16, "cycle_idx": 0, "tau": 3}]
     harness.write_jsonl(tmp_path / "o" / "out.jsonl", [row])
     assert json.loads(open(tmp_path / "o" / "out.jsonl").read()) == row
+
+
+@pytest.mark.gpu
+def test_cli_stdout_feeds_the_sweep_script(tmp_path):
+    """SURVEY.md §8f-3 end to end: `python -m dflash_amd.harness_cli` (benchmark.py's main on this
+    package's loop: bs = 1 baseline + speculative run per prompt) on the GPU; run_block_sweep.sh's
+    greps (:199-212) are applied to its REAL stdout with the script's own `grep -Eo ... | awk` forms,
+    and the JSONL files hold the rows of benchmark.py:503-534 / :481-497."""
+    import subprocess
+    import sys
+    out_p, tr_p = tmp_path / "o" / "out.jsonl", tmp_path / "o" / "trace.jsonl"
+    r = subprocess.run([sys.executable, "-m", "dflash_amd.harness_cli", "--synthetic", "tiny", "--max-samples", "3",
+                        "--max-new-tokens", "48", "--prompt-len", "40", "--scripted-tau", "5.0", "--collect-profile",
+                        "--save-outputs-path", str(out_p), "--save-cycle-trace-path", str(tr_p)],
+                       cwd=H.ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.splitlines()
+    for pat in SWEEP_PATTERNS:
+        assert any(re.search(pat, ln) for ln in lines), (pat, r.stdout[-1500:])
+    log = tmp_path / "bs16.log"
+    log.write_text(r.stdout)
+
+    def sweep_grep(expr, field):   # run_block_sweep.sh:199-204 verbatim form
+        sh = f"(grep -Eo '{expr}' '{log}' || true) | tail -1 | awk '{{print ${field}}}'"
+        return subprocess.run(["bash", "-c", sh], capture_output=True, text=True).stdout.strip()
+
+    speedup = float(sweep_grep("Decoding speedup: [0-9.]+$", 3))
+    tau = float(sweep_grep("Average Acceptance length: [0-9.]+$", 4))
+    tps = float(sweep_grep("Speculative tokens_per_sec: [0-9.]+$", 3))
+    base_tps = float(sweep_grep("Baseline tokens_per_sec: [0-9.]+$", 3))
+    assert speedup > 1.0 and 2.0 < tau < 9.0 and tps > base_tps > 0
+    rows = [json.loads(ln) for ln in open(out_p)]
+    assert len(rows) == 3 and [r_["dataset_row_idx"] for r_ in rows] == [0, 1, 2]
+    for row in rows:
+        assert list(row) == ["rank", "dataset_row_idx", "turn_index", "dataset", "prompt_text", "input_text",
+                             "block_size", "draft_steps", "baseline", "speculative"]
+        # lossless: the speculative text equals the bs = 1 baseline's (the target's own greedy continuation)
+        assert row["speculative"]["output_text"] == row["baseline"]["output_text"]
+        assert row["speculative"]["num_output_tokens"] == 48 and row["baseline"]["acceptance_lengths"] == [1] * 48
+        assert row["speculative"]["profile_summary"]["profiled_cycles"] == len(row["speculative"]["acceptance_lengths"])
+    tr = [json.loads(ln) for ln in open(tr_p)]
+    spec = [t for t in tr if t["mode"] == "speculative"]
+    assert {t["mode"] for t in tr} == {"baseline", "speculative"} and all(t["block_size"] in (1, 16) for t in tr)
+    assert {"cycle_idx", "generated_tokens_before", "effective_block_size", "tau", "acceptance_ratio", "draft_s",
+            "target_s", "cycle_s"} <= set(spec[0])
+    assert sum(t["tau"] for t in spec if t["dataset_row_idx"] == 0) >= 48

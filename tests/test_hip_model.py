@@ -45,21 +45,13 @@ def test_forward_matches_reference_vectors(tag, cfgf):
         hid = m(target_hidden=th, noise_embedding=ne, position_ids=pos, past_key_values=cache, use_cache=True,
                 is_causal=False)
         cache.crop(start)
-        ref = torch.from_numpy(z[f"hid{c}"])
-        got = hid.float().cpu()
-        assert got.shape == ref.shape
-        scale = ref.abs().max()
-        d = (got - ref).abs()
-        assert d.max() <= 4e-2 * scale, f"cycle {c}: max {d.max()} scale {scale}"
-        assert d.mean() <= 4e-3 * scale, f"cycle {c}: mean {d.mean()}"
+        H.assert_close(f"{tag} hidden cycle {c}", hid, torch.from_numpy(z[f"hid{c}"]))
     n = cache.get_seq_length()
     for li in (0, cfg.num_hidden_layers - 1):
         for name, buf in (("k", cache.k), ("v", cache.v)):
             ref = torch.from_numpy(z[f"{name}_l{li}"])[0]          # [kv, n, 128]
-            got = buf[li][:, :n].float().cpu()
             assert ref.shape[1] == n
-            d = (got - ref).abs()
-            assert d.max() <= 6e-2 * ref.abs().max() and d.mean() <= 4e-3 * ref.abs().max(), (name, li)
+            H.assert_close(f"{tag} cache {name} layer {li}", buf[li][:, :n], ref, max_rel=H.KV_MAX_REL)
 
 
 def _scripted(g, cfg, dtype=BF16):
@@ -201,14 +193,8 @@ def test_draft_tokens_match_oracle_tiny():
                              embed=emb.to(dev()))
         logits = torch.zeros(16, V, dtype=BF16, device=dev())
         m.draft_tokens(frag, lm_wp, bs, blk[0], logits=logits)
-        got = logits[1:bs].float().cpu()
-        scale = ref_logits.abs().max()
-        assert (got - ref_logits).abs().max() <= 4e-2 * scale
-        top2 = ref_logits.topk(2, dim=-1).values
-        safe = (top2[:, 0] - top2[:, 1]) > 8e-2 * scale
-        ref_ids = ref_logits.argmax(-1)
-        assert torch.equal(blk[0, 1:].cpu()[safe], ref_ids[safe])
-        assert (blk[0, 1:].cpu() == ref_ids).float().mean() >= 0.8
+        H.assert_close(f"mid draft logits start {start}", logits[1:bs], ref_logits)
+        H.assert_ids_match_where_safe(f"mid draft ids start {start}", blk[0, 1:], ref_logits, min_agree=0.8)
 
 
 # ------------------------------------------------------------------ native target verify
@@ -239,20 +225,14 @@ def test_native_verify_matches_hf_forward():
     ref = hf(block, position_ids=torch.arange(45, 61, device=dev())[None], past_key_values=rc, use_cache=True,
              output_hidden_states=True)
     rl = ref.logits[0].float()
-    scale = rl.abs().max()
-    assert (logits.float() - rl).abs().max() <= 4e-2 * scale
+    H.assert_close("tiny verify logits", logits, rl)
     assert torch.equal(post[0], torch.argmax(logits, dim=-1))
-    top2 = rl.topk(2, dim=-1).values
-    safe = (top2[:, 0] - top2[:, 1]) > 8e-2 * scale
-    assert torch.equal(post[0][safe], rl.argmax(-1)[safe])
+    H.assert_ids_match_where_safe("tiny verify ids", post[0], rl)
     for j, l in enumerate(taps):
-        r = ref.hidden_states[l + 1][0].float()
-        d = (th[:, j * 512:(j + 1) * 512].float() - r).abs()
-        assert d.max() <= 4e-2 * r.abs().max() and d.mean() <= 4e-3 * r.abs().max()
+        H.assert_close(f"tiny verify tap {l}", th[:, j * 512:(j + 1) * 512], ref.hidden_states[l + 1][0])
     for li in (0, 5):
-        for got, want in ((cache.k[li][:, :61], rc.layers[li].keys[0]), (cache.v[li][:, :61], rc.layers[li].values[0])):
-            d = (got.float() - want.float()).abs()
-            assert d.max() <= 6e-2 * want.float().abs().max() and d.mean() <= 4e-3 * want.float().abs().max()
+        H.assert_close(f"tiny verify K layer {li}", cache.k[li][:, :61], rc.layers[li].keys[0], max_rel=H.KV_MAX_REL)
+        H.assert_close(f"tiny verify V layer {li}", cache.v[li][:, :61], rc.layers[li].values[0], max_rel=H.KV_MAX_REL)
     assert cache.get_seq_length() == 61
     assert out0.logits.shape[1] == 1
 
@@ -373,13 +353,12 @@ def test_native_target_llama_style(rope):
     ref = hf(block, position_ids=torch.arange(29, 41, device=dev())[None], past_key_values=rc, use_cache=True,
              output_hidden_states=True)
     rl = ref.logits[0].float()
-    assert (logits[:12].float() - rl).abs().max() <= 4e-2 * rl.abs().max()
-    r = ref.hidden_states[2][0].float()
-    assert (taps[:12, :512].float() - r).abs().max() <= 4e-2 * r.abs().max()
+    tag = rope["rope_type"]
+    H.assert_close(f"llama-style {tag} logits", logits[:12], rl)
+    H.assert_close(f"llama-style {tag} tap", taps[:12, :512], ref.hidden_states[2][0])
     assert torch.equal(post[0], torch.argmax(logits[:12], dim=-1))
-    for got, want in ((cache.k[0][:, :41], rc.layers[0].keys[0]), (cache.k[3][:, :41], rc.layers[3].keys[0])):
-        d = (got.float() - want.float()).abs()   # K rows carry the RoPE: scaled frequencies included
-        assert d.max() <= 6e-2 * want.float().abs().max() and d.mean() <= 4e-3 * want.float().abs().max()
+    for li in (0, 3):    # K rows carry the RoPE: scaled frequencies included
+        H.assert_close(f"llama-style {tag} K layer {li}", cache.k[li][:, :41], rc.layers[li].keys[0], max_rel=H.KV_MAX_REL)
 
 
 def test_qwen3_4b_geometry_matches_oracle():
@@ -411,15 +390,12 @@ def test_qwen3_4b_geometry_matches_oracle():
         got = m(target_hidden=th.to(dev()), noise_embedding=ne.to(dev()), position_ids=pos.to(dev()),
                 past_key_values=cache, use_cache=True, is_causal=False)
         cache.crop(start)
-        d = (got.float().cpu() - ref.float()).abs()
-        scale = ref.float().abs().max()
-        assert d.max() <= 4e-2 * scale and d.mean() <= 4e-3 * scale, (c, float(d.max()), float(scale))
+        H.assert_close(f"4B-geometry draft hidden cycle {c}", got, ref)
         start += tau_next
     n = cache.get_seq_length()
     for li in range(cfg.num_hidden_layers):
-        for got, want in ((cache.k[li][:, :n], ocache.k[li][0]), (cache.v[li][:, :n], ocache.v[li][0])):
-            dd = (got.float().cpu() - want.float()).abs()
-            assert dd.max() <= 6e-2 * want.float().abs().max() and dd.mean() <= 4e-3 * want.float().abs().max()
+        H.assert_close(f"4B-geometry draft K layer {li}", cache.k[li][:, :n], ocache.k[li][0], max_rel=H.KV_MAX_REL)
+        H.assert_close(f"4B-geometry draft V layer {li}", cache.v[li][:, :n], ocache.v[li][0], max_rel=H.KV_MAX_REL)
 
 
     # ---- target side: a 4-layer HF Qwen3 of the same geometry through NativeTarget.verify
@@ -440,12 +416,9 @@ def test_qwen3_4b_geometry_matches_oracle():
     hf(prompt, past_key_values=rc, use_cache=True)
     refo = hf(block, position_ids=torch.arange(50, 66, device=dev())[None], past_key_values=rc, use_cache=True,
               output_hidden_states=True)
-    rl = refo.logits[0].float()
-    assert (logits.float() - rl).abs().max() <= 4e-2 * rl.abs().max()
+    H.assert_close("4B-geometry verify logits", logits, refo.logits[0])
     for j, li in enumerate((0, 2)):
-        r = refo.hidden_states[li + 1][0].float()
-        dd = (taps[:, j * 640:(j + 1) * 640].float() - r).abs()
-        assert dd.max() <= 4e-2 * r.abs().max() and dd.mean() <= 4e-3 * r.abs().max()
+        H.assert_close(f"4B-geometry verify tap {li}", taps[:, j * 640:(j + 1) * 640], refo.hidden_states[li + 1][0])
 
 
 def test_full_size_draft_cycle_matches_oracle():
@@ -475,20 +448,19 @@ def test_full_size_draft_cycle_matches_oracle():
         got = m(target_hidden=th.to(dev()), noise_embedding=ne.to(dev()), position_ids=pos.to(dev()),
                 past_key_values=cache, use_cache=True, is_causal=False)
         cache.crop(start)
-        d = (got.float().cpu() - ref.float()).abs()
-        scale = ref.float().abs().max()
-        assert d.max() <= 4e-2 * scale and d.mean() <= 4e-3 * scale, (c, float(d.max()), float(scale))
+        H.assert_close(f"8B draft hidden cycle {c}", got, ref)
         start += tau_next
     # lm_head at full vocabulary on the last cycle's hidden rows
     lm = (torch.randn(cfg.vocab_size, cfg.hidden_size, generator=g) * 0.02).to(BF16)
     ref_logits = torch.nn.functional.linear(ref[0, 1:], lm).float()
     wp = m.packed_lm_head(lm.to(dev()))
     ids = torch.zeros(16, dtype=torch.long, device=dev())
-    m.draft_tokens(m._src["final"], wp, 16, ids)
-    top2 = ref_logits.topk(2, dim=-1).values
-    safe = (top2[:, 0] - top2[:, 1]) > 8e-2 * ref_logits.abs().max()
-    assert torch.equal(ids[1:].cpu()[safe], ref_logits.argmax(-1)[safe])
-    assert (ids[1:].cpu() == ref_logits.argmax(-1)).float().mean() >= 0.6
+    logits = torch.zeros(16, cfg.vocab_size, dtype=BF16, device=dev())
+    m.draft_tokens(m._src["final"], wp, 16, ids, logits=logits)
+    H.assert_close("8B draft logits (V = 151936)", logits[1:], ref_logits)
+    # random weights: the top-2 margin of a 151936-way argmax is a few bf16 ulps, so the screen
+    # (margin > 3 % of the logit scale) keeps few rows; it must keep some, and those must agree
+    H.assert_ids_match_where_safe("8B draft ids", ids[1:], ref_logits, margin_rel=3e-2, min_agree=0.6)
 
 
 def test_long_prefix_many_key_splits():
@@ -509,8 +481,7 @@ def test_long_prefix_many_key_splits():
     rc = DynamicCache()
     hf(prompt, past_key_values=rc, use_cache=True)
     ref = hf(block, position_ids=torch.arange(P, P + 16, device=dev())[None], past_key_values=rc, use_cache=True)
-    rl = ref.logits[0].float()
-    assert (logits.float() - rl).abs().max() <= 4e-2 * rl.abs().max()
+    H.assert_close("S = 9000 verify logits", logits, ref.logits[0])
 
 
 def test_harness_options_on_native_target():
