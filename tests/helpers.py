@@ -173,8 +173,11 @@ class ScriptedTarget:
 # relative to the reference's scale, prints the achieved values (pytest -rP / -s shows them) and
 # appends them to gpurun_out/parity_errors.jsonl on the GPU box, so the stated tolerance can be
 # read against the measured headroom (VERDICT r1 weak #1d).
-MAX_REL, MEAN_REL = 4e-2, 4e-3      # of the reference tensor's max-abs; DESIGN.md §2
-KV_MAX_REL = 6e-2                   # cached K rows: one more RoPE rounding chain on top
+# Measured on MI355X (round 2, 84 comparisons, profiles/r2_parity_errors.jsonl): worst max-abs 2.1e-2 and worst
+# mean-abs 3.1e-3 of the reference's scale (8B-shaped draft hidden states against the bf16 oracle) — the spread the
+# reference's own bf16 backends show against each other (1.6-2.1e-2); cached K/V rows: 1.2e-2.
+MAX_REL, MEAN_REL = 3e-2, 4e-3      # of the reference tensor's max-abs; DESIGN.md §2
+KV_MAX_REL = 3e-2                   # cached K/V rows
 
 
 def _log_parity(rec: dict) -> None:
