@@ -104,7 +104,7 @@ def gpu_leg(args, rank, world, dev):
     target, perm = make_hf_target(dev, layers=args.target_layers)
     if not args.hf_verify:
         from dflash_amd import NativeTarget
-        target = NativeTarget(target)   # verify on the kernels, prefill through HF
+        target = NativeTarget(target, attn_impl=args.attn_impl)   # verify on the kernels, prefill through HF
     cfg = DFlashConfig(**{**QWEN3_8B_DRAFT, "num_target_layers": args.target_layers})
     draft = DFlashDraftModel(cfg, device=dev)
     # seeded init directly on the GPU (CPU generation of 1e9 normals costs a minute)
@@ -419,6 +419,8 @@ def main():
     ap.add_argument("--hf-verify", action="store_true",
                     help="verify through the HF/PyTorch target forward (round-1 configuration) instead of "
                          "dflash_amd.NativeTarget")
+    ap.add_argument("--attn-impl", choices=["head", "fused"], default="head",
+                    help="attention stage of the native verify: head = dfl_attn_head (round 2), fused = dfl_attn_fused (round 1)")
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="launcher plumbing only (tests/test_distributed_cpu.py): ranks rendezvous over gloo, run no "
                          "kernels and report value null; never a measurement")

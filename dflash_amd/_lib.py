@@ -52,6 +52,9 @@ SIGNATURES = {
     "dfl_attn_fused_ws_bytes": (_i64, [_i, _i, _i]),
     "dfl_attn_fused": (_i, [_p, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _f, _p, _p, _i, _p, _p, _i, _f, _i, _p,
                             _i, _p, _i, _p, _p]),
+    "dfl_attn_head_ws_bytes": (_i64, [_i, _i, _i]),
+    "dfl_attn_head": (_i, [_p, _i64, _i, _i, _i, _p, _i64, _i, _i, _i, _i, _p, _p, _f, _p, _p, _i, _p, _p, _i, _f, _i,
+                           _p, _i, _i, _i, _i, _i, _p, _i, _p, _i64, _p]),
     "dfl_argmax": (_i, [_p, _i, _i, _i64, _p, _p]),
     "dfl_accept_commit": (_i, [_p, _p, _i, _p, _i64, _p, _p, _i, _p, _p]),
     # ---- ragged batch of requests

@@ -1,0 +1,609 @@
+// Block attention, second form (round 2): the attention stage of one block in ONE launch, reading
+// the q/k/v projections as FINISHED bf16 Linear outputs (dfl_gemm_resid with add_residual = 0)
+// instead of fp32 K-split partials.  Replaces model/dflash.py:71-99 (q/k-norm, local RoPE of :22-28,
+// cache append, attention over cached prefix + context + block rows) and, with causal = 1, the same
+// stage of the target's verify forward (:249-255).
+//
+// Why a second form (profiles/r1_*: k_attn_fused = 19.6 us per launch for 4.3 MB of K/V): the first
+// form's critical path was  q prologue 4.4 -> new K/V rows 2.4 -> 4 LDS-staged tiles of one wave per
+// SIMD 5.8 -> release fence + ticket 2.3 -> 9-way merge of 32 KB partials by ONE workgroup 5.4 us.
+// This form removes each of those:
+//   * grid (kv head, G query heads x splits): a workgroup owns ONE query head, its 8 waves own
+//     disjoint 32-key tiles — no LDS staging shared between waves, no barrier in the tile loop:
+//     K fragments go HBM/L2 -> VGPR directly in MFMA A-operand order (a lane's 16 B = 8 consecutive
+//     d of one key; 16 keys x 64 B per load instruction, whole 256-B rows over the four k-steps),
+//     V rows go through a wave-private 8 KB LDS tile for the transposed read (ds_read_b64_tr_b16);
+//   * the G workgroups of a kv head have equal blockIdx.x = kv head: with 8 kv heads they share an
+//     XCD under round-robin placement, so the K/V rows they all read come from HBM once and from that
+//     XCD's L2 afterwards (speed only, never correctness);
+//   * the 8 waves' (m, l, O) meet in LDS (64 KB), so a workgroup publishes ONE 8 KB partial per
+//     query tile; at 1k keys that is 6 partials per head instead of 9 x 32 KB per kv head, merged by
+//     the last arriver of the HEAD (32 mergers side by side instead of 8);
+//   * partials are published with write-through (sc1) stores + drain + relaxed ticket and read back
+//     with sc1 loads: no release fence (L2 write-back) and no acquire (L1 invalidate) on the path
+//     (MI355X_MICROARCH.md, hand-off table row 1);
+//   * this cycle's new rows (context + block: <= 64) are a split of their own: its workgroups turn
+//     the rows into K/V (norm, RoPE) in LDS, attend over them from there, and the hh = 0 workgroup
+//     also appends them to the cache; no workgroup reads a cache row written in this launch;
+//   * lengths may come as immediates (host-driven loop) instead of a dependent scalar load.
+// MFMA: S^T = K Q^T and O^T += V^T P^T on v_mfma_f32_16x16x32_bf16 as in attn_block.hip (same
+// fragment layouts, same base-2 online softmax in fp32, P rounded to bf16 for the PV product).
+#include "dfl_common.h"
+#include <type_traits>
+
+namespace {
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+struct HeadAttnArgs {
+  const bf16_t *xq;  // block rows [bs][ldq]: q | k | v column blocks
+  int64_t ldq;
+  int q_col, k_col, v_col;
+  const bf16_t *xc;  // context rows [tau][ldc] (k, v only); may be null when tau == 0
+  int64_t ldc;
+  int ck_col, cv_col;
+  const bf16_t *q_w, *k_w;
+  float eps;
+  const bf16_t *cos_tab, *sin_tab;
+  int max_pos;
+  bf16_t *kc, *vc;
+  int cache_rows;
+  int n_q, n_kv, G;
+  float scale_log2;
+  int causal;
+  const int32_t *dyn;
+  int S, tau, bs, pos0;  // used when dyn == nullptr
+  bf16x8 *out_frag;
+  int64_t out_tile_stride;  // bf16x8 units between the frag16 buffers of the two query tiles
+  float *o_part;   // [ns][n_q][QT*16][128]
+  float *ml_part;  // [ns][n_q][QT*16][2]
+  int *tickets;    // [n_q]
+  int ns_old;      // splits over the cached (old) keys; split ns_old owns the new rows
+};
+
+// 64-lane butterflies on VALU: v_permlane16_swap / v_permlane32_swap (gfx950) instead of
+// ds_bpermute round trips (~100 cycles each on a lone wave).  swap16 exchanges the odd 16-lane rows of
+// its first operand with the even rows of the second; swap32 the upper half of the first with the lower
+// half of the second: started from two copies of x, the two results are x's rows {0,0,2,2} and
+// {1,1,3,3} (resp. halves {lo,lo} and {hi,hi}), whose max / sum is the xor-16 (xor-32) butterfly.
+// Inline asm, not __builtin_amdgcn_permlane{16,32}_swap: hipcc (ROCm 7.2) treats the builtin's two
+// results as equal when its operands are (it reasons per lane) and folds max(r0, r1) to r0.  The
+// s_nop covers the VALU-write -> permlane-swap-read hazard the compiler pads the same way.
+__device__ __forceinline__ void swap16(float &a, float &b) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void swap32(float &a, float &b) {
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float wave_g_max(float v) {  // max over the four 16-lane rows, in every lane
+  float a = v, b = v;
+  swap16(a, b);
+  a = b = fmaxf(a, b);
+  swap32(a, b);
+  return fmaxf(a, b);
+}
+__device__ __forceinline__ float wave_g_sum(float v) {
+  float a = v, b = v;
+  swap16(a, b);
+  a = b = a + b;
+  swap32(a, b);
+  return a + b;
+}
+
+// NP items per 16-lane group, an item = 128 values of one (row, head): lane c = l & 15 owns
+// d = 8c .. 8c+7.  Loads first (all in flight), then Linear-output values -> per-head RMSNorm
+// (Qwen3RMSNorm over head_dim, model/dflash.py:72,79; skipped when nw == nullptr) -> RoPE
+// (rotate_half pairs lane c with lane c^8: DPP row_ror:8), each product and sum rounded to bf16
+// where torch rounds (model/dflash.py:22-28).  src[p] == nullptr marks an absent item.
+template <int NP>
+__device__ __forceinline__ void rope_items(const bf16_t *const (&src)[NP], const int (&pos)[NP], const bool (&rope)[NP],
+                                           const bf16_t *nw, float eps, const bf16_t *cos_tab, const bf16_t *sin_tab,
+                                           int max_pos, const bf16_t *safe, int l, bf16x8 (&out)[NP]) {
+  const int c = l & 15, d0 = c * 8;
+  bf16x8 xv[NP], cs[NP], sn[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    xv[p] = *reinterpret_cast<const bf16x8 *>((src[p] ? src[p] : safe) + d0);
+    int pp = pos[p] < max_pos ? pos[p] : max_pos - 1;
+    pp = pp < 0 ? 0 : pp;
+    cs[p] = *reinterpret_cast<const bf16x8 *>(cos_tab + (int64_t)pp * 64 + (d0 & 63));
+    sn[p] = *reinterpret_cast<const bf16x8 *>(sin_tab + (int64_t)pp * 64 + (d0 & 63));
+  }
+  bf16x8 wv = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (nw) wv = *reinterpret_cast<const bf16x8 *>(nw + d0);
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    float x[8], n[8];
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      x[j] = bf2f(xv[p][j]);
+      ss += x[j] * x[j];
+    }
+    if (nw) {
+      ss += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, ss), 0xB1, 0xF, 0xF, true));
+      ss += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, ss), 0x4E, 0xF, 0xF, true));
+      ss += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, ss), 0x141, 0xF, 0xF, true));
+      ss += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, ss), 0x140, 0xF, 0xF, true));
+      const float rstd = rsqrtf(ss * (1.f / 128.f) + eps);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) n[j] = rbf(bf2f(wv[j]) * rbf(x[j] * rstd));
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) n[j] = x[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float pn =
+          __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, n[j]), 0x128, 0xF, 0xF, true));
+      const float cj = bf2f(cs[p][j]), sj = bf2f(sn[p][j]);
+      const float r = rbf(rbf(n[j] * cj) + rbf((c < 8 ? -pn : pn) * sj));
+      out[p][j] = f2bf(rope[p] ? r : x[j]);
+    }
+  }
+}
+
+__device__ __forceinline__ int k_swz(int row, int ch) { return row * 256 + ((ch ^ (row & 15)) << 4); }
+__device__ __forceinline__ int v_swz(int row, int ch) {
+  return row * 256 + ((((ch >> 1) ^ (row & 7)) << 5) | ((ch & 1) << 4));
+}
+
+template <int QT>
+struct HeadLds {
+  static constexpr int kVPriv = 8 * 8192;            // wave-private V tiles (old splits) | new K, new V (new split)
+  static constexpr int kQ = kVPriv;                  // q rows, swizzled like K: QT * 4 KB
+  static constexpr int kLoop = kVPriv + QT * 4096;
+  static constexpr int kMergeO = 0;                  // after the loop: 8 waves x QT x [16][128] fp32
+  static constexpr int kMergeML = 8 * QT * 8192;     // 8 waves x QT x [16][2] fp32
+  static constexpr int kMerge = kMergeML + 8 * QT * 128;
+  static constexpr int kRaw = kLoop > kMerge ? kLoop : kMerge;
+  // > 80 KB: one workgroup per CU, the geometry the sc1 hand-off is measured for
+  static constexpr int kBytes = kRaw > 84 * 1024 ? kRaw : 84 * 1024;
+};
+
+template <int QT>
+__global__ __launch_bounds__(512) void k_attn_head(HeadAttnArgs a) {
+  using L = HeadLds<QT>;
+  __shared__ __attribute__((aligned(16))) char lds[L::kBytes];
+  __shared__ int s_last;
+
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
+  const int kvh = blockIdx.x;
+  const int hh = (int)blockIdx.y % a.G, split = (int)blockIdx.y / a.G;
+  const int head = kvh * a.G + hh;
+  const int ns = a.ns_old + 1;
+  const bool is_new = split == a.ns_old;
+  int S = a.S, tau = a.tau, bs = a.bs, pos0 = a.pos0;
+  if (a.dyn) {
+    S = a.dyn[DFL_DYN_S];
+    tau = a.dyn[DFL_DYN_TAU];
+    bs = a.dyn[DFL_DYN_BS];
+    pos0 = a.dyn[DFL_DYN_POS0];
+  }
+  const int n_new = tau + bs;  // <= 64
+  const int qi = l & 15, g = l >> 4;
+
+  const bf16_t *kbase = a.kc + (int64_t)kvh * a.cache_rows * 128;
+  const bf16_t *vbase = a.vc + (int64_t)kvh * a.cache_rows * 128;
+
+  // ---- old-key tiles of this split; wave w walks t0 + w, t0 + w + 8, ...
+  int t0 = 0, t1 = 0;
+  if (!is_new && a.ns_old > 0) {
+    const int nt = (S + 31) >> 5;
+    const int tps = (nt + a.ns_old - 1) / a.ns_old;
+    t0 = split * tps;
+    t1 = t0 + tps;
+    t0 = t0 > nt ? nt : t0;
+    t1 = t1 > nt ? nt : t1;
+  }
+  const int old_last = S > 0 ? S - 1 : 0;
+  bf16x8 kA[2][4], vA[8], kB[2][4], vB[8];
+  // all loads of a tile are unconditional with clamped rows (they batch; rows >= S are masked
+  // below and never touch memory another workgroup writes in this launch)
+  auto fetch = [&](bf16x8(&kf)[2][4], bf16x8(&vr)[8], int t) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      int row = t * 32 + u * 16 + qi;
+      row = row < old_last ? row : old_last;
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        kf[u][s] = *reinterpret_cast<const bf16x8 *>(kbase + (int64_t)row * 128 + s * 32 + g * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = l + 64 * i;
+      int row = t * 32 + (c >> 4);
+      row = row < old_last ? row : old_last;
+      vr[i] = *reinterpret_cast<const bf16x8 *>(vbase + (int64_t)row * 128 + (c & 15) * 8);
+    }
+  };
+  int tcur = t0 + w;
+  if (tcur < t1) fetch(kA, vA, tcur);
+
+  // ---- q rows of this head: QT*16 items, 4 per wave per pass, written swizzled like a K tile
+  char *q_lds = lds + L::kQ;
+  {
+    const bf16_t *safe = a.xq;
+    for (int j0 = 4 * w; j0 < QT * 16; j0 += 32) {
+      const int j = j0 + g;
+      const bf16_t *src[1] = {j < bs ? a.xq + (int64_t)j * a.ldq + a.q_col + head * 128 : nullptr};
+      const int pos[1] = {pos0 + tau + j};
+      const bool rp[1] = {true};
+      bf16x8 ov[1];
+      rope_items<1>(src, pos, rp, a.q_w, a.eps, a.cos_tab, a.sin_tab, a.max_pos, safe, l, ov);
+      const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      *reinterpret_cast<bf16x8 *>(q_lds + (j >> 4) * 4096 + k_swz(j & 15, qi)) = j < bs ? ov[0] : z;
+    }
+  }
+
+  // ---- new split: this cycle's K / V rows of the kv head -> LDS tiles (and the cache, hh == 0)
+  char *new_k = lds, *new_v = lds + 16384;  // up to two 32-row tiles each
+  if (is_new) {
+    auto sweep = [&](auto np_tag) {
+      constexpr int NP = decltype(np_tag)::value;
+      const bf16_t *src[NP];
+      int pos[NP], rel[NP];
+      bool rp[NP], isv[NP];
+      bf16x8 ov[NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int it = (p * 8 + w) * 4 + g;  // 32 items per pass
+        isv[p] = it >= n_new;
+        rel[p] = isv[p] ? it - n_new : it;
+        const bool ok = it < 2 * n_new;
+        const bf16_t *row = rel[p] < tau ? a.xc + (int64_t)rel[p] * a.ldc + (isv[p] ? a.cv_col : a.ck_col)
+                                         : a.xq + (int64_t)(rel[p] - tau) * a.ldq + (isv[p] ? a.v_col : a.k_col);
+        src[p] = ok ? row + kvh * 128 : nullptr;
+        pos[p] = pos0 + rel[p];
+        rp[p] = !isv[p];
+      }
+      rope_items<NP>(src, pos, rp, a.k_w, a.eps, a.cos_tab, a.sin_tab, a.max_pos, a.xq, l, ov);
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+        if (src[p]) {
+          const int jt = rel[p] >> 5, r = rel[p] & 31;
+          *reinterpret_cast<bf16x8 *>((isv[p] ? new_v + jt * 8192 + v_swz(r, qi) : new_k + jt * 8192 + k_swz(r, qi))) = ov[p];
+          const int crow = S + rel[p];
+          if (hh == 0 && crow < a.cache_rows)
+            *reinterpret_cast<bf16x8 *>((isv[p] ? a.vc : a.kc) + ((int64_t)kvh * a.cache_rows + crow) * 128 + qi * 8) = ov[p];
+        }
+    };
+    if (2 * n_new <= 32)
+      sweep(std::integral_constant<int, 1>{});
+    else if (2 * n_new <= 64)
+      sweep(std::integral_constant<int, 2>{});
+    else
+      sweep(std::integral_constant<int, 4>{});
+  }
+  __syncthreads();
+
+  // Q^T B-fragments: lane (q = l&15, g) holds Q[q][32 s + 8 g .. +8]
+  bf16x8 qf[QT][4];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[qt][s] = *reinterpret_cast<const bf16x8 *>(q_lds + qt * 4096 + k_swz(qi, s * 4 + g));
+
+  f32x4 o[QT][8];
+  float m_run[QT], l_run[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    m_run[qt] = -INFINITY;
+    l_run[qt] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) o[qt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+
+  // one 32-key tile: K fragments in registers, V tile (swizzled rows) at vt in LDS.
+  // key0 = index of the tile's first key in its own numbering (old: cache row; new: rel);
+  // nvalid = keys of that numbering that exist; vrows = rows of the V tile holding real data.
+  auto compute = [&](const bf16x8(&kf)[2][4], const char *vt, int key0, int nvalid, int vrows, bool new_rows) {
+    const int qq = qi >> 2, p4 = l & 3;
+    int r0 = 4 * g + qq, r1 = 16 + 4 * g + qq;
+    r0 = r0 < vrows ? r0 : vrows - 1;  // rows past the data hold stale LDS bytes: P is 0 there, but 0 x NaN is not
+    r1 = r1 < vrows ? r1 : vrows - 1;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      f32x4 sc[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        sc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) sc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[u][s], qf[qt][s], sc[u], 0, 0, 0);
+      }
+      // lane (q, g): sc[u][r] is key key0 + u*16 + 4g + r
+      float mx = -INFINITY;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = key0 + u * 16 + 4 * g + r;
+          // causal (target verify): query row j sees new row rel <= tau + j; cached rows always
+          const bool vis = key < nvalid && (!new_rows || !a.causal || key <= tau + qt * 16 + qi);
+          const float v = vis ? sc[u][r] * a.scale_log2 : -INFINITY;
+          sc[u][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = wave_g_max(mx);
+      const float m_new = fmaxf(m_run[qt], mx);
+      const float m_ref = m_new == -INFINITY ? 0.f : m_new;
+      const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_ref);
+      m_run[qt] = m_new;
+      float psum = 0.f;
+      bf16x8 pb;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __builtin_amdgcn_exp2f(sc[u][r] - m_ref);
+          psum += p;
+          pb[u * 4 + r] = f2bf(p);
+        }
+      l_run[qt] = l_run[qt] * alpha + psum;
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) o[qt][dt] *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) {
+        const bf16x4 v0 =
+            __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(vt + r0 * 256 + (((dt ^ (r0 & 7)) << 5) | (p4 << 3))));
+        const bf16x4 v1 =
+            __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(vt + r1 * 256 + (((dt ^ (r1 & 7)) << 5) | (p4 << 3))));
+        const bf16x8 va = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb, o[qt][dt], 0, 0, 0);
+      }
+    }
+  };
+
+  if (is_new) {
+    const int ntile = (n_new + 31) >> 5;  // 1 or 2
+    if (w < ntile) {
+      bf16x8 kf[2][4];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          kf[u][s] = *reinterpret_cast<const bf16x8 *>(new_k + w * 8192 + k_swz(u * 16 + qi, s * 4 + g));
+      int vrows = n_new - w * 32;
+      vrows = vrows > 32 ? 32 : vrows;
+      compute(kf, new_v + w * 8192, w * 32, n_new, vrows, true);
+    }
+  } else {
+    char *my_v = lds + w * 8192;
+    auto put_v = [&](const bf16x8(&vr)[8]) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = l + 64 * i;
+        *reinterpret_cast<bf16x8 *>(my_v + v_swz(c >> 4, c & 15)) = vr[i];
+      }
+    };
+    // the wave's own LDS tile: its ds_write -> ds_read order is program order (lgkmcnt), no barrier
+    for (; tcur < t1; tcur += 16) {
+      if (tcur + 8 < t1) fetch(kB, vB, tcur + 8);
+      put_v(vA);
+      compute(kA, my_v, tcur * 32, S, 32, false);
+      if (tcur + 8 >= t1) break;
+      if (tcur + 16 < t1) fetch(kA, vA, tcur + 16);
+      put_v(vB);
+      compute(kB, my_v, (tcur + 8) * 32, S, 32, false);
+    }
+  }
+
+  // ---- the 8 waves meet in LDS
+  __syncthreads();
+  {
+    float *mo = reinterpret_cast<float *>(lds + L::kMergeO);
+    float *mml = reinterpret_cast<float *>(lds + L::kMergeML);
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      const float lt = wave_g_sum(l_run[qt]);
+      float *op = mo + ((w * QT + qt) * 16 + qi) * 128;
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) *reinterpret_cast<f32x4 *>(op + dt * 16 + 4 * g) = o[qt][dt];
+      if (g == 0) {
+        mml[((w * QT + qt) * 16 + qi) * 2] = m_run[qt];
+        mml[((w * QT + qt) * 16 + qi) * 2 + 1] = lt;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid >= QT * 256) {  // QT = 1: the upper 4 waves have no item (they still join the barriers below)
+    if (ns == 1) return;
+  }
+  const bool has_item = tid < QT * 256;
+  const int qt = tid >> 8, q = (tid >> 4) & 15, dg = tid & 15;
+  float M = -INFINITY, Lsum = 0.f, acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  if (has_item) {
+    const float *mo = reinterpret_cast<const float *>(lds + L::kMergeO);
+    const float *mml = reinterpret_cast<const float *>(lds + L::kMergeML);
+    float ms[8], ls[8];
+#pragma unroll
+    for (int ww = 0; ww < 8; ++ww) {
+      ms[ww] = mml[((ww * QT + qt) * 16 + q) * 2];
+      ls[ww] = mml[((ww * QT + qt) * 16 + q) * 2 + 1];
+      M = fmaxf(M, ms[ww]);
+    }
+    const float mref = M == -INFINITY ? 0.f : M;
+#pragma unroll
+    for (int ww = 0; ww < 8; ++ww) {  // fixed wave order: reproducible sums
+      const float wgt = __builtin_amdgcn_exp2f(ms[ww] - mref);  // exp2(-inf) = 0: a wave without tiles
+      const float *op = mo + ((ww * QT + qt) * 16 + q) * 128 + dg * 8;
+      const f32x4 a0 = *reinterpret_cast<const f32x4 *>(op), a1 = *reinterpret_cast<const f32x4 *>(op + 4);
+      Lsum += wgt * ls[ww];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[j] += wgt * a0[j];
+        acc[4 + j] += wgt * a1[j];
+      }
+    }
+  }
+  auto emit = [&](float Lt, const float(&v)[8]) {  // frag16 chunk (n>>3 = head*16 + dg, row q) of query tile qt
+    const float inv = Lt > 0.f ? 1.f / Lt : 0.f;
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = f2bf(v[j] * inv);
+    a.out_frag[qt * a.out_tile_stride + (head * 16 + dg) * 16 + q] = r;
+  };
+  if (ns == 1) {
+    if (has_item) emit(Lsum, acc);
+    return;
+  }
+
+  // ---- publish the workgroup's partial write-through, drain, ticket; the head's last arriver merges
+  const size_t item_row = (size_t)head * (QT * 16) + qt * 16 + q;
+  const size_t rows_per_split = (size_t)a.n_q * (QT * 16);
+  const __amdgpu_buffer_rsrc_t ro =
+      __builtin_amdgcn_make_buffer_rsrc(a.o_part, 0, (int)(rows_per_split * ns * 128 * sizeof(float)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rm =
+      __builtin_amdgcn_make_buffer_rsrc(a.ml_part, 0, (int)(rows_per_split * ns * 2 * sizeof(float)), 0x00020000);
+  if (has_item) {
+    const int off = (int)((((size_t)split * rows_per_split + item_row) * 128 + dg * 8) * sizeof(float));
+    const f32x4 s0 = {acc[0], acc[1], acc[2], acc[3]}, s1 = {acc[4], acc[5], acc[6], acc[7]};
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, s0), ro, off, 0, 16);  // sc1
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, s1), ro, off + 16, 0, 16);
+    if (dg == 0) {
+      const int offm = (int)((((size_t)split * rows_per_split + item_row) * 2) * sizeof(float));
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, M), rm, offm, 0, 16);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, Lsum), rm, offm + 4, 0, 16);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    const int ticket = __hip_atomic_fetch_add(&a.tickets[head], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = ticket == ns - 1;
+    if (last) __hip_atomic_store(&a.tickets[head], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
+    s_last = last;
+  }
+  __syncthreads();
+  if (!s_last || !has_item) return;
+
+  // every load of the handed-off bytes is an sc1 load (L2-served): no acquire needed
+  {
+    float Mg = -INFINITY, Lg = 0.f, ag[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ag[j] = 0.f;
+    constexpr int U = 4;
+    for (int s = 0; s < ns; s += U) {
+      float ms[U], ls[U];
+      f32x4 a0[U], a1[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int sc = s + u < ns ? s + u : ns - 1;
+        const int off = (int)((((size_t)sc * rows_per_split + item_row) * 128 + dg * 8) * sizeof(float));
+        const int offm = (int)((((size_t)sc * rows_per_split + item_row) * 2) * sizeof(float));
+        ms[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, offm, 0, 16));
+        ls[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, offm + 4, 0, 16));
+        a0[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ro, off, 0, 16));
+        a1[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ro, off + 16, 0, 16));
+      }
+      float mnew = Mg;
+#pragma unroll
+      for (int u = 0; u < U; ++u) mnew = fmaxf(mnew, s + u < ns ? ms[u] : -INFINITY);
+      const float mref = mnew == -INFINITY ? 0.f : mnew;
+      const float scale = __builtin_amdgcn_exp2f(Mg - mref);
+      Mg = mnew;
+      Lg *= scale;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ag[j] *= scale;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {  // fixed split order
+        const float wgt = s + u < ns ? __builtin_amdgcn_exp2f(ms[u] - mref) : 0.f;
+        Lg += wgt * ls[u];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          ag[j] += wgt * a0[u][j];
+          ag[4 + j] += wgt * a1[u][j];
+        }
+      }
+    }
+    emit(Lg, ag);
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t dfl_attn_head_ws_bytes(int n_q, int max_splits, int q_tiles) {
+  return (int64_t)max_splits * n_q * q_tiles * 16 * (128 + 2) * sizeof(float) + (int64_t)n_q * sizeof(int) + 64;
+}
+
+extern "C" int dfl_attn_head(const void *xq, int64_t ldq, int q_col, int k_col, int v_col, const void *xc, int64_t ldc,
+                             int ck_col, int cv_col, int n_q, int n_kv, const void *q_norm_w, const void *k_norm_w,
+                             float eps, const void *cos_tab, const void *sin_tab, int max_pos, void *kcache,
+                             void *vcache, int cache_rows, float scale, int causal, const int32_t *dyn, int S, int tau,
+                             int bs, int pos0, int q_tiles, void *ws, int max_splits, void *out_frag,
+                             int64_t out_tile_stride, void *stream) {
+  DFL_REQUIRE(xq && cos_tab && sin_tab && kcache && vcache && out_frag && ws, "dfl_attn_head: null pointer");
+  DFL_REQUIRE((q_norm_w == nullptr) == (k_norm_w == nullptr), "dfl_attn_head: give both norm weights or neither");
+  DFL_REQUIRE(n_q > 0 && n_kv > 0 && n_q % n_kv == 0, "dfl_attn_head: bad head counts (n_q=%d n_kv=%d)", n_q, n_kv);
+  DFL_REQUIRE(q_tiles == 1 || q_tiles == 2, "dfl_attn_head: q_tiles must be 1 or 2");
+  DFL_REQUIRE(ldq > 0 && ldq % 8 == 0 && q_col >= 0 && k_col >= 0 && v_col >= 0 && q_col % 8 == 0 && k_col % 8 == 0 &&
+                  v_col % 8 == 0 && max_pos > 0,
+              "dfl_attn_head: bad block-row layout");
+  DFL_REQUIRE(S >= 0 && tau >= 0 && tau <= 32 && bs >= 1 && bs <= 16 * q_tiles && tau + bs <= 64,
+              "dfl_attn_head: lengths S=%d tau=%d bs=%d outside the kernel's range (q_tiles=%d)", S, tau, bs, q_tiles);
+  DFL_REQUIRE(tau == 0 || (xc && ldc > 0 && ldc % 8 == 0 && ck_col >= 0 && cv_col >= 0 && ck_col % 8 == 0 && cv_col % 8 == 0),
+              "dfl_attn_head: context rows without a context source");
+  DFL_REQUIRE(S + tau + bs <= cache_rows, "dfl_attn_head: S + tau + bs = %d exceeds cache_rows = %d", S + tau + bs, cache_rows);
+  DFL_REQUIRE(max_splits >= 1 && out_tile_stride >= 0 && out_tile_stride % 8 == 0, "dfl_attn_head: bad max_splits / out_tile_stride");
+  // Old-key splits: a workgroup's 8 waves take one 32-key tile each per round, so up to 8 tiles
+  // per split cost one round; beyond ~224 workgroups per launch the splits grow instead
+  // (S here is the bound the caller sized the launch for when the lengths come from dyn).
+  const int G = n_q / n_kv;
+  const int nt = (S + 31) / 32;
+#ifndef DFL_ATTN_HEAD_TILES
+#define DFL_ATTN_HEAD_TILES 8
+#endif
+  int ns_old = (nt + DFL_ATTN_HEAD_TILES - 1) / DFL_ATTN_HEAD_TILES;
+  int budget = 224 / n_q - 1;
+  budget = budget < 1 ? 1 : budget;
+  ns_old = ns_old > budget ? budget : ns_old;
+  ns_old = ns_old > max_splits - 1 ? max_splits - 1 : ns_old;
+  if (nt == 0 && !dyn) ns_old = 0;
+  HeadAttnArgs a{};
+  a.xq = (const bf16_t *)xq;
+  a.ldq = ldq;
+  a.q_col = q_col;
+  a.k_col = k_col;
+  a.v_col = v_col;
+  a.xc = (const bf16_t *)xc;
+  a.ldc = ldc;
+  a.ck_col = ck_col;
+  a.cv_col = cv_col;
+  a.q_w = (const bf16_t *)q_norm_w;
+  a.k_w = (const bf16_t *)k_norm_w;
+  a.eps = eps;
+  a.cos_tab = (const bf16_t *)cos_tab;
+  a.sin_tab = (const bf16_t *)sin_tab;
+  a.max_pos = max_pos;
+  a.kc = (bf16_t *)kcache;
+  a.vc = (bf16_t *)vcache;
+  a.cache_rows = cache_rows;
+  a.n_q = n_q;
+  a.n_kv = n_kv;
+  a.G = G;
+  a.scale_log2 = scale * 1.4426950408889634f;
+  a.causal = causal ? 1 : 0;
+  a.dyn = dyn;
+  a.S = S;
+  a.tau = tau;
+  a.bs = bs;
+  a.pos0 = pos0;
+  a.out_frag = (bf16x8 *)out_frag;
+  a.out_tile_stride = out_tile_stride / 8;
+  const int64_t rows = (int64_t)max_splits * n_q * q_tiles * 16;
+  a.o_part = (float *)ws;
+  a.ml_part = (float *)ws + rows * 128;
+  a.tickets = (int *)((float *)ws + rows * 130);
+  a.ns_old = ns_old;
+  const dim3 grid(n_kv, G * (ns_old + 1));
+  hipStream_t st = (hipStream_t)stream;
+  if (q_tiles == 1)
+    hipLaunchKernelGGL(k_attn_head<1>, grid, dim3(512), 0, st, a);
+  else
+    hipLaunchKernelGGL(k_attn_head<2>, grid, dim3(512), 0, st, a);
+  DFL_CHECK_LAUNCH("dfl_attn_head");
+  return DFL_OK;
+}

@@ -248,6 +248,31 @@ def attn_fused(*, qkv, nsplit, split_stride, ld, q_col, k_col, v_col, ctx_row0, 
         _p(out_frag, BF16, "out_frag"), _stream()), "dfl_attn_fused")
 
 
+def attn_head_ws(n_q: int, max_splits: int, q_tiles: int, device) -> torch.Tensor:
+    """Zeroed workspace (split partials + arrival tickets) for attn_head."""
+    return torch.zeros(lib().dfl_attn_head_ws_bytes(n_q, max_splits, q_tiles), dtype=torch.uint8, device=device)
+
+
+def attn_head(*, xq: torch.Tensor, q_col: int, k_col: int, v_col: int, n_q: int, n_kv: int, q_norm_w, k_norm_w, eps,
+              cos_tab, sin_tab, kcache, vcache, scale: float, causal: bool, S: int, tau: int, bs: int, pos0: int,
+              ws, max_splits: int, out_frag: torch.Tensor, xc: Optional[torch.Tensor] = None, ck_col: int = 0,
+              cv_col: int = 0, dyn: Optional[torch.Tensor] = None, q_tiles: int = 1, out_tile_stride: int = 0) -> None:
+    """xq [>= bs, ldq] bf16 rows (unit inner stride) holding q | k | v of the block rows; xc [>= tau, ldc] the
+    context rows' k | v (draft).  dyn given: lengths from the device record, S = bound for the split count."""
+    assert xq.is_cuda and xq.dtype == BF16 and xq.dim() == 2 and xq.stride(1) == 1 and xq.shape[0] >= min(bs, 16 * q_tiles)
+    assert kcache.shape == vcache.shape and kcache.dim() == 3 and kcache.shape[2] == 128
+    xcp, ldc = None, 0
+    if xc is not None:
+        assert xc.is_cuda and xc.dtype == BF16 and xc.dim() == 2 and xc.stride(1) == 1 and xc.shape[0] >= tau
+        xcp, ldc = xc.data_ptr(), xc.stride(0)
+    check(lib().dfl_attn_head(
+        xq.data_ptr(), xq.stride(0), q_col, k_col, v_col, xcp, ldc, ck_col, cv_col, n_q, n_kv,
+        _p(q_norm_w, BF16, "q_norm_w"), _p(k_norm_w, BF16, "k_norm_w"), eps, _p(cos_tab, BF16, "cos"),
+        _p(sin_tab, BF16, "sin"), cos_tab.shape[0], _p(kcache, BF16, "kcache"), _p(vcache, BF16, "vcache"),
+        kcache.shape[1], scale, int(causal), _p(dyn, I32, "dyn"), S, tau, bs, pos0, q_tiles, _p(ws), max_splits,
+        _p(out_frag, BF16, "out_frag"), out_tile_stride, _stream()), "dfl_attn_head")
+
+
 def argmax(logits: torch.Tensor) -> torch.Tensor:
     """First-max-index argmax over the last axis, int64 (model/utils.py:28-29)."""
     if logits.dtype not in (BF16, F32):

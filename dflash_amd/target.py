@@ -50,7 +50,13 @@ class TargetKVCache:
 
 
 class NativeTarget:
-    def __init__(self, hf_model, max_splits: int = 32):
+    def __init__(self, hf_model, max_splits: int = 32, attn_impl: str = "head"):
+        """attn_impl: "head" = dfl_attn_head on finished bf16 q/k/v rows (round 2, default); "fused" = the
+        round-1 stage (fp32 K-split partials -> dfl_attn_fused), kept for A/B measurement and as a second
+        implementation the tests compare against."""
+        if attn_impl not in ("head", "fused"):
+            raise ValueError("attn_impl must be 'head' or 'fused'")
+        self.attn_impl = attn_impl
         cfg = hf_model.config
         self.hf = hf_model
         self.model = hf_model.model
@@ -117,6 +123,7 @@ class NativeTarget:
                        ss_emb=z(16, dt=torch.float32), ss_h=z(self.H, dt=torch.float32),
                        q=z(self.n_q, 16, 128), part=z(npart, dt=torch.float32),
                        attn_ws=ops.attn_fused_ws(self.n_q, self.n_kv, max_splits, dev), argmax_ws=ops.argmax_ws(dev),
+                       xq=z(16, self.nqkv), head_ws=ops.attn_head_ws(self.n_q, max_splits, 1, dev),
                        post=torch.zeros(16, dtype=torch.int64, device=dev))
         ws, nt = self.ws, self.H // 16
         # row sources: the consuming GEMM applies the RMSNorm itself (no norm launches)
@@ -212,13 +219,23 @@ class NativeTarget:
         Ls, src = self.layers, self.src
         ops.embed_rows(self.embed, block_ids, ws["h"], H, ws["ss_emb"], dyn, ops.DYN_BS)
         for i, lw in enumerate(Ls):
-            ops.gemm_f32(lw["qkv"], src["ln1"][i], None, 1, self.nqkv, H, self.ks_qkv, ws["part"], dyn)
-            ops.attn_fused(qkv=ws["part"], nsplit=self.ks_qkv, split_stride=16 * self.nqkv, ld=self.nqkv, q_col=0,
-                           k_col=self.q_dim, v_col=self.q_dim + self.kv_dim, ctx_row0=0, blk_row0=0, n_q=self.n_q,
-                           n_kv=self.n_kv, q_norm_w=lw["q_norm"], k_norm_w=lw["k_norm"], eps=self.eps, cos_tab=cos,
-                           sin_tab=sin, kcache=cache.k[i], vcache=cache.v[i], dyn=dyn, scale=128 ** -0.5,
-                           kv_len_max=start + bs, ws=ws["attn_ws"], max_splits=self.max_splits, out_frag=ws["attn"],
-                           causal=True)
+            if self.attn_impl == "head":
+                # q/k/v as finished bf16 Linear outputs (no K split: 192 workgroups x 2 column tiles), then
+                # one launch: q/k-norm + RoPE + append + causal attention + split merge
+                ops.gemm_resid(lw["qkv"], src["ln1"][i], self.nqkv, H, ws["xq"], add_residual=False, dyn=dyn)
+                ops.attn_head(xq=ws["xq"], q_col=0, k_col=self.q_dim, v_col=self.q_dim + self.kv_dim, n_q=self.n_q,
+                              n_kv=self.n_kv, q_norm_w=lw["q_norm"], k_norm_w=lw["k_norm"], eps=self.eps, cos_tab=cos,
+                              sin_tab=sin, kcache=cache.k[i], vcache=cache.v[i], scale=128 ** -0.5, causal=True,
+                              S=start, tau=0, bs=bs, pos0=start, ws=ws["head_ws"], max_splits=self.max_splits,
+                              out_frag=ws["attn"])
+            else:
+                ops.gemm_f32(lw["qkv"], src["ln1"][i], None, 1, self.nqkv, H, self.ks_qkv, ws["part"], dyn)
+                ops.attn_fused(qkv=ws["part"], nsplit=self.ks_qkv, split_stride=16 * self.nqkv, ld=self.nqkv, q_col=0,
+                               k_col=self.q_dim, v_col=self.q_dim + self.kv_dim, ctx_row0=0, blk_row0=0, n_q=self.n_q,
+                               n_kv=self.n_kv, q_norm_w=lw["q_norm"], k_norm_w=lw["k_norm"], eps=self.eps,
+                               cos_tab=cos, sin_tab=sin, kcache=cache.k[i], vcache=cache.v[i], dyn=dyn,
+                               scale=128 ** -0.5, kv_len_max=start + bs, ws=ws["attn_ws"],
+                               max_splits=self.max_splits, out_frag=ws["attn"], causal=True)
             ops.gemm_resid(lw["o"], src["attn"], H, self.q_dim, ws["h"], add_residual=True, ss_out=ws["ss_h"],
                            dyn=dyn)
             ops.gemm_silu_mul(lw["gu"], src["ln2"][i], self.I, H, ws["act"], dyn)

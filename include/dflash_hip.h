@@ -203,6 +203,25 @@ int dfl_attn_fused(const float *qkv, int nsplit, int64_t split_stride, int ld, i
                    int cache_rows, float scale, int causal, const int32_t *dyn, int kv_len_max, void *ws,
                    int max_splits, void *out_frag, void *stream);
 
+/* The attention stage, second form: same arithmetic as dfl_attn_fused (model/dflash.py:71-99; causal = 1: the
+ * target verify's stage, :249-255), but q/k/v arrive as FINISHED bf16 Linear outputs — dfl_gemm_resid(add_residual
+ * = 0) of the block rows into xq [bs][ldq] (q | k | v column blocks at q_col / k_col / v_col) and, for the draft,
+ * of the context rows into xc [tau][ldc] (k, v at ck_col / cv_col; xc may be NULL when tau == 0) — and the grid is
+ * (kv head, query heads of the group x key splits): one query head per workgroup, 8 waves over disjoint 32-key
+ * tiles with no barrier in the loop, wave results merged in LDS, one 8 KB partial per workgroup published
+ * write-through and merged by the head's last arriver (csrc/attn_head.hip).  New rows (tau + bs <= 64, tau <= 32)
+ * are appended to the cache at rows S.. by the launch itself.  bs <= 16 * q_tiles, q_tiles in {1, 2}: the second
+ * query tile's frag16 output lies out_tile_stride bf16 elements after the first.
+ * Lengths: dyn == NULL -> the immediates S, tau, bs, pos0; else they are read from dyn and S is the caller's
+ * upper bound on dyn[S] (it sizes the key splits, as kv_len_max does for dfl_attn_fused).
+ * ws: dfl_attn_head_ws_bytes(n_q, max_splits, q_tiles) bytes, ZEROED once (arrival tickets, left zero). */
+int64_t dfl_attn_head_ws_bytes(int n_q, int max_splits, int q_tiles);
+int dfl_attn_head(const void *xq, int64_t ldq, int q_col, int k_col, int v_col, const void *xc, int64_t ldc,
+                  int ck_col, int cv_col, int n_q, int n_kv, const void *q_norm_w, const void *k_norm_w, float eps,
+                  const void *cos_tab, const void *sin_tab, int max_pos, void *kcache, void *vcache, int cache_rows,
+                  float scale, int causal, const int32_t *dyn, int S, int tau, int bs, int pos0, int q_tiles,
+                  void *ws, int max_splits, void *out_frag, int64_t out_tile_stride, void *stream);
+
 /* First-max-index argmax over the last axis (model/utils.py:28-29).
  * dtype: 0 = bf16, 1 = fp32.  ids int64 [rows]. */
 int dfl_argmax(const void *logits, int dtype, int rows, int64_t V, int64_t *ids, void *stream);

@@ -458,6 +458,125 @@ def test_attn_fused_equals_three_launch_path(ops, n_q, n_kv, S, tau, bs, causal)
     assert (b - ref).abs().max() <= 2 ** -6 * ref.abs().max()
 
 
+@pytest.mark.parametrize("n_q,n_kv,S,tau,bs,causal,use_dyn", [
+    (4, 2, 0, 3, 16, False, False), (8, 2, 37, 5, 12, False, True), (32, 8, 1024, 7, 16, False, False),
+    (32, 8, 1041, 0, 16, True, False), (32, 4, 300, 16, 16, False, False), (4, 4, 70, 2, 9, False, True),
+    (8, 2, 3000, 16, 16, True, True), (32, 8, 9001, 11, 16, False, False), (4, 2, 0, 0, 16, True, False),
+    (8, 8, 255, 16, 5, True, False), (32, 8, 31, 1, 1, True, True)])
+def test_attn_head_equals_three_launch_path(ops, n_q, n_kv, S, tau, bs, causal, use_dyn):
+    """dfl_attn_head (finished bf16 q/k/v rows in, one launch, one query head per workgroup, wave results
+    merged in LDS, sc1 partials) against dfl_qknorm_rope_append + dfl_block_attn fed with the SAME Linear
+    outputs, and against fp32 torch: appended V bit-identical, K up to rare 1-ulp flips, output within the
+    rounding of a different key-split order.  Lengths as immediates and from the device record; GQA groups
+    1, 2, 4, 8; zero cached keys; more splits than max_splits allows (S = 9001)."""
+    from dflash_amd.model import _rope_tables
+    g = gen(S + n_q + bs + 7)
+    ld = (n_q + 2 * n_kv) * 128
+    x = torch.randn(32, ld, generator=g).to(BF16).to(dev())           # rows 0..15 context, 16..31 block
+    part = x.float()[None].contiguous()                                  # the same values as one fp32 "partial"
+    qw = (1 + 0.1 * torch.randn(128, generator=g)).to(BF16).to(dev())
+    kw = (1 + 0.1 * torch.randn(128, generator=g)).to(BF16).to(dev())
+    cos, sin = _rope_tables(128, 1e6, 16384, dev())
+    rows = S + tau + bs + 8
+    k0 = torch.randn(n_kv, rows, 128, generator=g).to(BF16).to(dev())
+    v0 = torch.randn(n_kv, rows, 128, generator=g).to(BF16).to(dev())
+    dyn = torch.zeros(8, dtype=torch.int32, device=dev())
+    ops.set_dyn(dyn, S, tau, bs, S)
+    k1, v1 = k0.clone(), v0.clone()
+    q1 = torch.zeros(n_q, 16, 128, dtype=BF16, device=dev())
+    out1 = torch.zeros(16 * n_q * 128, dtype=BF16, device=dev())
+    ops.qknorm_rope_append(qkv=part, nsplit=1, split_stride=32 * ld, ld=ld, q_col=0, k_col=n_q * 128,
+                           v_col=(n_q + n_kv) * 128, ctx_row0=0, blk_row0=16, n_q=n_q, n_kv=n_kv, q_norm_w=qw,
+                           k_norm_w=kw, eps=1e-6, cos_tab=cos, sin_tab=sin, dyn=dyn, q_out=q1, kcache=k1, vcache=v1)
+    ops.block_attn(q=q1, kcache=k1, vcache=v1, n_q=n_q, n_kv=n_kv, scale=128 ** -0.5, dyn=dyn,
+                   kv_len_max=S + tau + bs, ws=ops.attn_ws(n_q, 32, dev()), max_splits=32, out_frag=out1,
+                   causal=causal)
+    k2, v2 = k0.clone(), v0.clone()
+    out2 = torch.zeros(16 * n_q * 128, dtype=BF16, device=dev())
+    hws = ops.attn_head_ws(n_q, 8, 1, dev())
+    for _ in range(2):   # twice: the arrival tickets must be back at zero after a launch
+        out2.fill_(float("nan"))
+        ops.attn_head(xq=x[16:], q_col=0, k_col=n_q * 128, v_col=(n_q + n_kv) * 128, xc=x[:16], ck_col=n_q * 128,
+                      cv_col=(n_q + n_kv) * 128, n_q=n_q, n_kv=n_kv, q_norm_w=qw, k_norm_w=kw, eps=1e-6, cos_tab=cos,
+                      sin_tab=sin, kcache=k2, vcache=v2, scale=128 ** -0.5, causal=causal, S=S, tau=tau, bs=bs, pos0=S,
+                      dyn=dyn if use_dyn else None, ws=hws, max_splits=8, out_frag=out2)
+    assert torch.equal(v1, v2)
+    dk = (k1.float() - k2.float()).abs()
+    assert (dk > 0).float().mean() < 1e-3 and dk.max() <= 2 ** -7 * k1.float().abs().max()
+    a = unfrag(out1, n_q * 128).float()[:bs]
+    b = unfrag(out2, n_q * 128).float()[:bs]
+    assert torch.isfinite(b).all()
+    assert (a - b).abs().max() <= 2 ** -6 * a.abs().max()
+    kv_len = S + tau + bs
+    G = n_q // n_kv
+    kk = k2[:, :kv_len].float().repeat_interleave(G, dim=0)
+    vv = v2[:, :kv_len].float().repeat_interleave(G, dim=0)
+    sc = torch.einsum("hqd,hkd->hqk", q1[:, :bs].float(), kk) * 128 ** -0.5
+    if causal:
+        mask = torch.arange(kv_len, device=dev())[None, :] > (S + tau + torch.arange(bs, device=dev()))[:, None]
+        sc = sc.masked_fill(mask[None], float("-inf"))
+    ref = torch.einsum("hqk,hkd->qhd", torch.softmax(sc, dim=-1), vv).reshape(bs, n_q * 128)
+    assert (b - ref).abs().max() <= 2 ** -6 * ref.abs().max()
+
+
+@pytest.mark.parametrize("n_q,n_kv,S,tau,bs,causal", [(8, 2, 90, 0, 29, True), (32, 8, 1030, 20, 24, False),
+                                                      (4, 2, 0, 32, 32, False), (32, 4, 70, 5, 17, True)])
+def test_attn_head_two_query_tiles(ops, n_q, n_kv, S, tau, bs, causal):
+    """Blocks of 17..32 rows (results.md:11-16 sweeps 20 and 24): two 16-row query tiles per workgroup, up to
+    64 new rows (two LDS tiles), against fp32 torch computed from the kernel's own q-norm/RoPE reference
+    (dfl_qknorm_rope_append run per 16-row tile)."""
+    from dflash_amd.model import _rope_tables
+    g = gen(S + n_q + bs + 3)
+    ld = (n_q + 2 * n_kv) * 128
+    xc = torch.randn(32, ld, generator=g).to(BF16).to(dev())
+    xq = torch.randn(32, ld, generator=g).to(BF16).to(dev())
+    qw = (1 + 0.1 * torch.randn(128, generator=g)).to(BF16).to(dev())
+    kw = (1 + 0.1 * torch.randn(128, generator=g)).to(BF16).to(dev())
+    cos, sin = _rope_tables(128, 1e6, 4096, dev())
+    rows = S + tau + bs + 8
+    k0 = torch.randn(n_kv, rows, 128, generator=g).to(BF16).to(dev())
+    v0 = torch.randn(n_kv, rows, 128, generator=g).to(BF16).to(dev())
+    # reference K/V/q rows from the row-wise kernel, 16 rows at a time (context tiles, then block tiles)
+    k1, v1 = k0.clone(), v0.clone()
+    q1 = torch.zeros(2, n_q, 16, 128, dtype=BF16, device=dev())
+    dyn = torch.zeros(8, dtype=torch.int32, device=dev())
+    done = 0
+    for src, n, is_blk in ((xc, tau, False), (xq, bs, True)):
+        for r0 in range(0, n, 16):
+            nr = min(16, n - r0)
+            buf = torch.zeros(32, ld, dtype=torch.float32, device=dev())
+            buf[16 if is_blk else 0:][:nr] = src[r0:r0 + nr].float()
+            ops.set_dyn(dyn, S + done, 0 if is_blk else nr, nr if is_blk else 0, S + done)
+            ops.qknorm_rope_append(qkv=buf[None].contiguous(), nsplit=1, split_stride=32 * ld, ld=ld, q_col=0,
+                                   k_col=n_q * 128, v_col=(n_q + n_kv) * 128, ctx_row0=0, blk_row0=16, n_q=n_q, n_kv=n_kv,
+                                   q_norm_w=qw, k_norm_w=kw, eps=1e-6, cos_tab=cos, sin_tab=sin, dyn=dyn,
+                                   q_out=q1[r0 // 16] if is_blk else q1[0].clone(), kcache=k1, vcache=v1)
+            done += nr
+    k2, v2 = k0.clone(), v0.clone()
+    out2 = torch.full((2, 16 * n_q * 128), float("nan"), dtype=BF16, device=dev())
+    hws = ops.attn_head_ws(n_q, 8, 2, dev())
+    ops.attn_head(xq=xq, q_col=0, k_col=n_q * 128, v_col=(n_q + n_kv) * 128, xc=xc, ck_col=n_q * 128,
+                  cv_col=(n_q + n_kv) * 128, n_q=n_q, n_kv=n_kv, q_norm_w=qw, k_norm_w=kw, eps=1e-6, cos_tab=cos,
+                  sin_tab=sin, kcache=k2, vcache=v2, scale=128 ** -0.5, causal=causal, S=S, tau=tau, bs=bs, pos0=S,
+                  ws=hws, max_splits=8, out_frag=out2, q_tiles=2, out_tile_stride=out2.stride(0))
+    kv_len = S + tau + bs
+    assert torch.equal(v1[:, :kv_len], v2[:, :kv_len])
+    dk = (k1[:, :kv_len].float() - k2[:, :kv_len].float()).abs()
+    assert (dk > 0).float().mean() < 1e-3 and dk.max() <= 2 ** -7 * k1.float().abs().max()
+    G = n_q // n_kv
+    kk = k2[:, :kv_len].float().repeat_interleave(G, dim=0)
+    vv = v2[:, :kv_len].float().repeat_interleave(G, dim=0)
+    qq = torch.cat([q1[0], q1[1]], dim=1)[:, :bs].float()               # [n_q, bs, 128]
+    sc = torch.einsum("hqd,hkd->hqk", qq, kk) * 128 ** -0.5
+    if causal:
+        mask = torch.arange(kv_len, device=dev())[None, :] > (S + tau + torch.arange(bs, device=dev()))[:, None]
+        sc = sc.masked_fill(mask[None], float("-inf"))
+    ref = torch.einsum("hqk,hkd->qhd", torch.softmax(sc, dim=-1), vv).reshape(bs, n_q * 128)
+    got = torch.cat([unfrag(out2[0], n_q * 128), unfrag(out2[1], n_q * 128)]).float()[:bs]
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max() <= 2 ** -6 * ref.abs().max()
+
+
 # ------------------------------------------------------------------ integer side, golden
 def test_argmax_golden(ops):
     z = np.load(os.path.join(H.GOLDEN, "argmax.npz"))
