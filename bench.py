@@ -107,6 +107,7 @@ def gpu_leg(args, rank, world, dev):
         target = NativeTarget(target, attn_impl=args.attn_impl)   # verify on the kernels, prefill through HF
     cfg = DFlashConfig(**{**QWEN3_8B_DRAFT, "num_target_layers": args.target_layers})
     draft = DFlashDraftModel(cfg, device=dev)
+    draft.attn_impl = args.attn_impl
     # seeded init directly on the GPU (CPU generation of 1e9 normals costs a minute)
     g = torch.Generator(device=dev).manual_seed(0)
     sd = {k: (torch.randn(s, generator=g, device=dev, dtype=torch.float32) * 0.02).to(torch.bfloat16)

@@ -37,6 +37,7 @@ SIGNATURES = {
     "dfl_pack_weight": (_i, [_p, _p, _i, _i, _p]),
     "dfl_pack_weight_gateup": (_i, [_p, _p, _p, _i, _i, _p]),
     "dfl_set_dyn": (_i, [_p, _i, _i, _i, _i, _p]),
+    "dfl_set_dyn2": (_i, [_p, _i, _i, _i, _i, _p]),
     "dfl_pack_rows": (_i, [_p, _i64, _i, _i, _p, _p, _i, _p]),
     "dfl_gemm_f32": (_i, [_p, _r, _r, _i, _i, _i, _i, _p, _p, _p]),
     "dfl_gemm_silu_mul": (_i, [_p, _r, _i, _i, _p, _p, _p]),

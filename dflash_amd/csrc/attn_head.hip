@@ -29,6 +29,7 @@
 // MFMA: S^T = K Q^T and O^T += V^T P^T on v_mfma_f32_16x16x32_bf16 as in attn_block.hip (same
 // fragment layouts, same base-2 online softmax in fp32, P rounded to bf16 for the PV product).
 #include "dfl_common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -96,38 +97,50 @@ __device__ __forceinline__ float wave_g_sum(float v) {
 // (rotate_half pairs lane c with lane c^8: DPP row_ror:8), each product and sum rounded to bf16
 // where torch rounds (model/dflash.py:22-28).  src[p] == nullptr marks an absent item.
 template <int NP>
-__device__ __forceinline__ void rope_items(const bf16_t *const (&src)[NP], const int (&pos)[NP], const bool (&rope)[NP],
-                                           const bf16_t *nw, float eps, const bf16_t *cos_tab, const bf16_t *sin_tab,
-                                           int max_pos, const bf16_t *safe, int l, bf16x8 (&out)[NP]) {
-  const int c = l & 15, d0 = c * 8;
-  bf16x8 xv[NP], cs[NP], sn[NP];
+struct RopeLoads {
+  bf16x8 xv[NP], cs[NP], sn[NP], wv;
+};
+
+// issue: the loads only (row values, cos/sin rows, norm weight).  A wave's vector loads return in issue
+// order, so these few KB are requested BEFORE the K/V tile burst and arrive within one round trip.
+template <int NP>
+__device__ __forceinline__ void rope_issue(const bf16_t *const (&src)[NP], const int (&pos)[NP], const bf16_t *nw,
+                                           const bf16_t *cos_tab, const bf16_t *sin_tab, int max_pos, const bf16_t *safe,
+                                           int l, RopeLoads<NP> &ld) {
+  const int d0 = (l & 15) * 8;
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
-    xv[p] = *reinterpret_cast<const bf16x8 *>((src[p] ? src[p] : safe) + d0);
+    ld.xv[p] = *reinterpret_cast<const bf16x8 *>((src[p] ? src[p] : safe) + d0);
     int pp = pos[p] < max_pos ? pos[p] : max_pos - 1;
     pp = pp < 0 ? 0 : pp;
-    cs[p] = *reinterpret_cast<const bf16x8 *>(cos_tab + (int64_t)pp * 64 + (d0 & 63));
-    sn[p] = *reinterpret_cast<const bf16x8 *>(sin_tab + (int64_t)pp * 64 + (d0 & 63));
+    ld.cs[p] = *reinterpret_cast<const bf16x8 *>(cos_tab + (int64_t)pp * 64 + (d0 & 63));
+    ld.sn[p] = *reinterpret_cast<const bf16x8 *>(sin_tab + (int64_t)pp * 64 + (d0 & 63));
   }
-  bf16x8 wv = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (nw) wv = *reinterpret_cast<const bf16x8 *>(nw + d0);
+  // unconditional (a load under a branch makes hipcc wait vmcnt(0) at the join): no norm -> 16 B nobody uses
+  ld.wv = *reinterpret_cast<const bf16x8 *>((nw ? nw : safe) + d0);
+}
+
+template <int NP>
+__device__ __forceinline__ void rope_finish(const RopeLoads<NP> &ld, const bool (&rope)[NP], bool has_norm, float eps, int l,
+                                            bf16x8 (&out)[NP]) {
+  const int c = l & 15;
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
     float x[8], n[8];
     float ss = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      x[j] = bf2f(xv[p][j]);
+      x[j] = bf2f(ld.xv[p][j]);
       ss += x[j] * x[j];
     }
-    if (nw) {
+    if (has_norm) {
       ss += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, ss), 0xB1, 0xF, 0xF, true));
       ss += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, ss), 0x4E, 0xF, 0xF, true));
       ss += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, ss), 0x141, 0xF, 0xF, true));
       ss += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, ss), 0x140, 0xF, 0xF, true));
       const float rstd = rsqrtf(ss * (1.f / 128.f) + eps);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) n[j] = rbf(bf2f(wv[j]) * rbf(x[j] * rstd));
+      for (int j = 0; j < 8; ++j) n[j] = rbf(bf2f(ld.wv[j]) * rbf(x[j] * rstd));
     } else {
 #pragma unroll
       for (int j = 0; j < 8; ++j) n[j] = x[j];
@@ -136,11 +149,20 @@ __device__ __forceinline__ void rope_items(const bf16_t *const (&src)[NP], const
     for (int j = 0; j < 8; ++j) {
       const float pn =
           __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, n[j]), 0x128, 0xF, 0xF, true));
-      const float cj = bf2f(cs[p][j]), sj = bf2f(sn[p][j]);
+      const float cj = bf2f(ld.cs[p][j]), sj = bf2f(ld.sn[p][j]);
       const float r = rbf(rbf(n[j] * cj) + rbf((c < 8 ? -pn : pn) * sj));
       out[p][j] = f2bf(rope[p] ? r : x[j]);
     }
   }
+}
+
+template <int NP>
+__device__ __forceinline__ void rope_items(const bf16_t *const (&src)[NP], const int (&pos)[NP], const bool (&rope)[NP],
+                                           const bf16_t *nw, float eps, const bf16_t *cos_tab, const bf16_t *sin_tab,
+                                           int max_pos, const bf16_t *safe, int l, bf16x8 (&out)[NP]) {
+  RopeLoads<NP> ld;
+  rope_issue<NP>(src, pos, nw, cos_tab, sin_tab, max_pos, safe, l, ld);
+  rope_finish<NP>(ld, rope, nw != nullptr, eps, l, out);
 }
 
 __device__ __forceinline__ int k_swz(int row, int ch) { return row * 256 + ((ch ^ (row & 15)) << 4); }
@@ -148,13 +170,29 @@ __device__ __forceinline__ int v_swz(int row, int ch) {
   return row * 256 + ((((ch >> 1) ^ (row & 7)) << 5) | ((ch & 1) << 4));
 }
 
+#ifdef DFL_ATTN_STAMPS  // diagnostic build only (scripts/dbg_attn_head_stamps.py): 100 MHz wall stamps of lane 0 of
+// workgroup (kv head 0, query head 0) of the first old-key split [0] and of the new-row split [1]
+__device__ unsigned long long g_hstamps[2][8];
+#define HSTAMP(i)                                                                                  \
+  do {                                                                                             \
+    if (tid == 0 && kvh == 0 && hh == 0 && (split == 0 || is_new))                                 \
+      g_hstamps[is_new ? 1 : 0][i] = __builtin_amdgcn_s_memrealtime();                             \
+  } while (0)
+#else
+#define HSTAMP(i)
+#endif
+
 template <int QT>
 struct HeadLds {
   static constexpr int kVPriv = 8 * 8192;            // wave-private V tiles (old splits) | new K, new V (new split)
   static constexpr int kQ = kVPriv;                  // q rows, swizzled like K: QT * 4 KB
   static constexpr int kLoop = kVPriv + QT * 4096;
-  static constexpr int kMergeO = 0;                  // after the loop: 8 waves x QT x [16][128] fp32
-  static constexpr int kMergeML = 8 * QT * 8192;     // 8 waves x QT x [16][2] fp32
+  // after the loop: 8 waves x QT x [16][kRow] fp32, rows padded 128 -> 132 floats: the 16 query rows of a wave's
+  // ds_write_b128 (and of the merge's ds_read_b128) then fall on different banks (unpadded: 8-way conflicts,
+  // 2.3 us of the stage)
+  static constexpr int kRow = 132;
+  static constexpr int kMergeO = 0;
+  static constexpr int kMergeML = 8 * QT * 16 * kRow * 4;  // 8 waves x QT x [16][2] fp32
   static constexpr int kMerge = kMergeML + 8 * QT * 128;
   static constexpr int kRaw = kLoop > kMerge ? kLoop : kMerge;
   // > 80 KB: one workgroup per CU, the geometry the sc1 hand-off is measured for
@@ -183,6 +221,7 @@ __global__ __launch_bounds__(512) void k_attn_head(HeadAttnArgs a) {
   }
   const int n_new = tau + bs;  // <= 64
   const int qi = l & 15, g = l >> 4;
+  HSTAMP(0);
 
   const bf16_t *kbase = a.kc + (int64_t)kvh * a.cache_rows * 128;
   const bf16_t *vbase = a.vc + (int64_t)kvh * a.cache_rows * 128;
@@ -218,28 +257,40 @@ __global__ __launch_bounds__(512) void k_attn_head(HeadAttnArgs a) {
       vr[i] = *reinterpret_cast<const bf16x8 *>(vbase + (int64_t)row * 128 + (c & 15) * 8);
     }
   };
-  int tcur = t0 + w;
-  if (tcur < t1) fetch(kA, vA, tcur);
-
-  // ---- q rows of this head: QT*16 items, 4 per wave per pass, written swizzled like a K tile
+  // ---- q rows of this head: QT*16 items, 4 per wave (waves 0 .. 4*QT-1), written swizzled like a K tile.
+  // Their loads go out first, the first K/V tile's behind them (vmcnt is in order), the arithmetic after both.
   char *q_lds = lds + L::kQ;
+  const int jq = 4 * w + g;  // this 16-lane group's q row (QT = 1: waves 0..3 hold rows, the others a dummy)
+  RopeLoads<1> qld;
   {
-    const bf16_t *safe = a.xq;
-    for (int j0 = 4 * w; j0 < QT * 16; j0 += 32) {
-      const int j = j0 + g;
-      const bf16_t *src[1] = {j < bs ? a.xq + (int64_t)j * a.ldq + a.q_col + head * 128 : nullptr};
-      const int pos[1] = {pos0 + tau + j};
+    const bf16_t *src[1] = {jq < bs ? a.xq + (int64_t)jq * a.ldq + a.q_col + head * 128 : nullptr};
+    const int pos[1] = {pos0 + tau + jq};
+    rope_issue<1>(src, pos, a.q_w, a.cos_tab, a.sin_tab, a.max_pos, a.xq, l, qld);
+  }
+  // (compiler fences: without them hipcc hoists the K/V burst above the q loads and sinks the norm-weight load
+  // into a branch of the arithmetic, and the q rows wait for the whole burst after all)
+  asm volatile("" ::: "memory");
+  auto finish_q = [&]() {
+    if (jq < QT * 16) {
       const bool rp[1] = {true};
       bf16x8 ov[1];
-      rope_items<1>(src, pos, rp, a.q_w, a.eps, a.cos_tab, a.sin_tab, a.max_pos, safe, l, ov);
+      rope_finish<1>(qld, rp, a.q_w != nullptr, a.eps, l, ov);
       const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-      *reinterpret_cast<bf16x8 *>(q_lds + (j >> 4) * 4096 + k_swz(j & 15, qi)) = j < bs ? ov[0] : z;
+      *reinterpret_cast<bf16x8 *>(q_lds + (jq >> 4) * 4096 + k_swz(jq & 15, qi)) = jq < bs ? ov[0] : z;
     }
-  }
-
-  // ---- new split: this cycle's K / V rows of the kv head -> LDS tiles (and the cache, hh == 0)
+  };
+  int tcur = t0 + w;
   char *new_k = lds, *new_v = lds + 16384;  // up to two 32-row tiles each
-  if (is_new) {
+  if (!is_new) {
+    // the first tile's loads are issued by EVERY wave of an old split, with or without a tile (clamped rows of
+    // valid cache memory): under a per-wave branch the compiler loses count of what is in flight and makes the q
+    // arithmetic wait for the whole K/V burst instead of for its own four loads
+    fetch(kA, vA, tcur < t1 ? tcur : 0);
+    asm volatile("" ::: "memory");
+    finish_q();
+  } else {
+    // ---- new split: this cycle's K / V rows of the kv head -> LDS tiles (and the cache, hh == 0).  Its loads go
+    // out right behind the q loads (no K/V tile burst in this workgroup), then q, then the rows.
     auto sweep = [&](auto np_tag) {
       constexpr int NP = decltype(np_tag)::value;
       const bf16_t *src[NP];
@@ -252,13 +303,20 @@ __global__ __launch_bounds__(512) void k_attn_head(HeadAttnArgs a) {
         isv[p] = it >= n_new;
         rel[p] = isv[p] ? it - n_new : it;
         const bool ok = it < 2 * n_new;
-        const bf16_t *row = rel[p] < tau ? a.xc + (int64_t)rel[p] * a.ldc + (isv[p] ? a.cv_col : a.ck_col)
-                                         : a.xq + (int64_t)(rel[p] - tau) * a.ldq + (isv[p] ? a.v_col : a.k_col);
+        // (arithmetic, not a select between two argument FIELDS: hipcc turns such a select into a select of their
+        // addresses plus a per-lane global load with vmcnt(0) — four dependent round trips in this prologue)
+        const int vsel = isv[p] ? 1 : 0;
+        const bf16_t *row = rel[p] < tau ? a.xc + (int64_t)rel[p] * a.ldc + a.ck_col + vsel * (a.cv_col - a.ck_col)
+                                         : a.xq + (int64_t)(rel[p] - tau) * a.ldq + a.k_col + vsel * (a.v_col - a.k_col);
         src[p] = ok ? row + kvh * 128 : nullptr;
         pos[p] = pos0 + rel[p];
         rp[p] = !isv[p];
       }
-      rope_items<NP>(src, pos, rp, a.k_w, a.eps, a.cos_tab, a.sin_tab, a.max_pos, a.xq, l, ov);
+      RopeLoads<NP> kld;
+      rope_issue<NP>(src, pos, a.k_w, a.cos_tab, a.sin_tab, a.max_pos, a.xq, l, kld);
+      asm volatile("" ::: "memory");
+      finish_q();
+      rope_finish<NP>(kld, rp, a.k_w != nullptr, a.eps, l, ov);
 #pragma unroll
       for (int p = 0; p < NP; ++p)
         if (src[p]) {
@@ -276,6 +334,7 @@ __global__ __launch_bounds__(512) void k_attn_head(HeadAttnArgs a) {
     else
       sweep(std::integral_constant<int, 4>{});
   }
+  HSTAMP(1);
   __syncthreads();
 
   // Q^T B-fragments: lane (q = l&15, g) holds Q[q][32 s + 8 g .. +8]
@@ -390,14 +449,16 @@ __global__ __launch_bounds__(512) void k_attn_head(HeadAttnArgs a) {
   }
 
   // ---- the 8 waves meet in LDS
+  HSTAMP(2);
   __syncthreads();
+  HSTAMP(3);
   {
     float *mo = reinterpret_cast<float *>(lds + L::kMergeO);
     float *mml = reinterpret_cast<float *>(lds + L::kMergeML);
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
       const float lt = wave_g_sum(l_run[qt]);
-      float *op = mo + ((w * QT + qt) * 16 + qi) * 128;
+      float *op = mo + ((w * QT + qt) * 16 + qi) * L::kRow;
 #pragma unroll
       for (int dt = 0; dt < 8; ++dt) *reinterpret_cast<f32x4 *>(op + dt * 16 + 4 * g) = o[qt][dt];
       if (g == 0) {
@@ -429,7 +490,7 @@ __global__ __launch_bounds__(512) void k_attn_head(HeadAttnArgs a) {
 #pragma unroll
     for (int ww = 0; ww < 8; ++ww) {  // fixed wave order: reproducible sums
       const float wgt = __builtin_amdgcn_exp2f(ms[ww] - mref);  // exp2(-inf) = 0: a wave without tiles
-      const float *op = mo + ((ww * QT + qt) * 16 + q) * 128 + dg * 8;
+      const float *op = mo + ((ww * QT + qt) * 16 + q) * L::kRow + dg * 8;
       const f32x4 a0 = *reinterpret_cast<const f32x4 *>(op), a1 = *reinterpret_cast<const f32x4 *>(op + 4);
       Lsum += wgt * ls[ww];
 #pragma unroll
@@ -446,6 +507,7 @@ __global__ __launch_bounds__(512) void k_attn_head(HeadAttnArgs a) {
     for (int j = 0; j < 8; ++j) r[j] = f2bf(v[j] * inv);
     a.out_frag[qt * a.out_tile_stride + (head * 16 + dg) * 16 + q] = r;
   };
+  HSTAMP(4);
   if (ns == 1) {
     if (has_item) emit(Lsum, acc);
     return;
@@ -471,6 +533,7 @@ __global__ __launch_bounds__(512) void k_attn_head(HeadAttnArgs a) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  HSTAMP(5);
   if (tid == 0) {
     const int ticket = __hip_atomic_fetch_add(&a.tickets[head], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = ticket == ns - 1;
@@ -478,6 +541,7 @@ __global__ __launch_bounds__(512) void k_attn_head(HeadAttnArgs a) {
     s_last = last;
   }
   __syncthreads();
+  HSTAMP(6);
   if (!s_last || !has_item) return;
 
   // every load of the handed-off bytes is an sc1 load (L2-served): no acquire needed
@@ -485,7 +549,7 @@ __global__ __launch_bounds__(512) void k_attn_head(HeadAttnArgs a) {
     float Mg = -INFINITY, Lg = 0.f, ag[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) ag[j] = 0.f;
-    constexpr int U = 4;
+    constexpr int U = 8;  // at 1k keys ns = 5 or 6: one round trip
     for (int s = 0; s < ns; s += U) {
       float ms[U], ls[U];
       f32x4 a0[U], a1[U];
@@ -521,9 +585,17 @@ __global__ __launch_bounds__(512) void k_attn_head(HeadAttnArgs a) {
     }
     emit(Lg, ag);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  HSTAMP(7);
 }
 
 }  // namespace
+
+#ifdef DFL_ATTN_STAMPS
+extern "C" int dfl_debug_read_head_stamps(unsigned long long *host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_hstamps), sizeof(unsigned long long) * 16);
+}
+#endif
 
 extern "C" int64_t dfl_attn_head_ws_bytes(int n_q, int max_splits, int q_tiles) {
   return (int64_t)max_splits * n_q * q_tiles * 16 * (128 + 2) * sizeof(float) + (int64_t)n_q * sizeof(int) + 64;
@@ -553,11 +625,13 @@ extern "C" int dfl_attn_head(const void *xq, int64_t ldq, int q_col, int k_col, 
   // (S here is the bound the caller sized the launch for when the lengths come from dyn).
   const int G = n_q / n_kv;
   const int nt = (S + 31) / 32;
-#ifndef DFL_ATTN_HEAD_TILES
-#define DFL_ATTN_HEAD_TILES 8
-#endif
-  int ns_old = (nt + DFL_ATTN_HEAD_TILES - 1) / DFL_ATTN_HEAD_TILES;
-  int budget = 224 / n_q - 1;
+  // (DFL_ATTN_HEAD_TILES / DFL_ATTN_HEAD_WGS: tuning knobs read once from the environment, for
+  // scripts/dbg_attn_head_stamps.py; the defaults are the measured choice)
+  static const int knob_tiles = [] { const char *e = getenv("DFL_ATTN_HEAD_TILES"); return e ? atoi(e) : 8; }();
+  static const int knob_wgs = [] { const char *e = getenv("DFL_ATTN_HEAD_WGS"); return e ? atoi(e) : 224; }();
+  const int tiles = knob_tiles < 1 ? 1 : knob_tiles;
+  int ns_old = (nt + tiles - 1) / tiles;
+  int budget = knob_wgs / n_q - 1;
   budget = budget < 1 ? 1 : budget;
   ns_old = ns_old > budget ? budget : ns_old;
   ns_old = ns_old > max_splits - 1 ? max_splits - 1 : ns_old;

@@ -20,6 +20,24 @@ __global__ void k_set_dyn(int32_t *dyn, int S, int tau, int bs, int pos0) {
   }
 }
 
+// Two records for a block of up to 32 rows handled as two 16-row tiles: record t holds the valid-row counts of
+// tile t (rows 16 t ..), everything else as k_set_dyn.
+__global__ void k_set_dyn2(int32_t *dyn, int S, int tau, int bs, int pos0) {
+  const int t = threadIdx.x;
+  if (t < 2) {
+    int32_t *d = dyn + t * DFL_DYN_WORDS;
+    const int tt = tau - 16 * t, bb = bs - 16 * t;
+    d[DFL_DYN_S] = S;
+    d[DFL_DYN_TAU] = tt < 0 ? 0 : (tt > 16 ? 16 : tt);
+    d[DFL_DYN_BS] = bb < 0 ? 0 : (bb > 16 ? 16 : bb);
+    d[DFL_DYN_POS0] = pos0;
+    d[DFL_DYN_START] = pos0 + tau;
+    d[DFL_DYN_STOP] = 0;
+    d[DFL_DYN_CYCLE] = 0;
+    d[7] = 0;
+  }
+}
+
 // one 16-B chunk per thread: frag[(k8*16 + m)*8 ..] = x[m][k8*8 ..]
 __global__ void k_pack_rows(const bf16_t *__restrict__ x, int64_t ldx, int rows, int K8, bf16x8 *__restrict__ xf,
                             const int32_t *dyn, int dyn_word) {
@@ -260,10 +278,19 @@ __global__ __launch_bounds__(256) void k_qknorm_rope(RopeArgs a_in) {
 
 extern "C" int dfl_set_dyn(int32_t *dyn, int S, int tau, int bs, int pos0, void *stream) {
   DFL_REQUIRE(dyn, "dfl_set_dyn: null pointer");
-  DFL_REQUIRE(S >= 0 && tau >= 0 && bs >= 0 && bs <= 16 && pos0 >= 0, "dfl_set_dyn: bad lengths S=%d tau=%d bs=%d pos0=%d", S,
+  DFL_REQUIRE(S >= 0 && tau >= 0 && bs >= 0 && bs <= 63 && pos0 >= 0, "dfl_set_dyn: bad lengths S=%d tau=%d bs=%d pos0=%d", S,
               tau, bs, pos0);
   hipLaunchKernelGGL(k_set_dyn, dim3(1), dim3(64), 0, (hipStream_t)stream, dyn, S, tau, bs, pos0);
   DFL_CHECK_LAUNCH("dfl_set_dyn");
+  return DFL_OK;
+}
+
+extern "C" int dfl_set_dyn2(int32_t *dyn, int S, int tau, int bs, int pos0, void *stream) {
+  DFL_REQUIRE(dyn, "dfl_set_dyn2: null pointer");
+  DFL_REQUIRE(S >= 0 && tau >= 0 && tau <= 32 && bs >= 0 && bs <= 32 && pos0 >= 0,
+              "dfl_set_dyn2: bad lengths S=%d tau=%d bs=%d pos0=%d", S, tau, bs, pos0);
+  hipLaunchKernelGGL(k_set_dyn2, dim3(1), dim3(64), 0, (hipStream_t)stream, dyn, S, tau, bs, pos0);
+  DFL_CHECK_LAUNCH("dfl_set_dyn2");
   return DFL_OK;
 }
 

@@ -26,7 +26,7 @@ from . import ops
 from .utils import extract_context_feature, sample
 
 _TABLES = {}
-MAX_BLOCK = 16  # rows per block the kernels take
+MAX_BLOCK = 32  # rows per block the kernels take: two 16-row tiles
 
 
 def cuda_time() -> float:
@@ -118,7 +118,7 @@ class DecodeSession:
         self.events = None  # set to a dict to have cycle() record (start, end) event pairs per phase
         # the tapped rows live here from a verify to the next draft (own buffer: several
         # sessions may be interleaved on one NativeTarget)
-        self.taps_buf = (torch.zeros(16, len(model.target_layer_ids) * model.config.hidden_size, dtype=torch.bfloat16,
+        self.taps_buf = (torch.zeros(32, len(model.target_layer_ids) * model.config.hidden_size, dtype=torch.bfloat16,
                                      device=dev) if (self.native and self.use_draft) else None)
 
     @torch.inference_mode()
@@ -317,7 +317,7 @@ def _draft_ids(model, hid_frag, lm_wp, bs, blk, draft_temperature):
         model.draft_tokens(hid_frag, lm_wp, bs, blk[0])
         return
     V = model.config.vocab_size
-    logits = torch.empty(16, V, dtype=torch.bfloat16, device=model.device)
+    logits = torch.empty(16 * ((bs + 15) // 16), V, dtype=torch.bfloat16, device=model.device)
     model.draft_tokens(hid_frag, lm_wp, bs, blk[0], logits=logits)
     blk[:, 1:bs] = sample(logits[1:bs].unsqueeze(0), draft_temperature)
 

@@ -46,7 +46,7 @@ class DFlashKVCache:
         L, kv = cfg.num_hidden_layers, cfg.num_key_value_heads
         self.k = torch.zeros(L, kv, self.max_rows, cfg.head_dim, dtype=BF16, device=device)
         self.v = torch.zeros_like(self.k)
-        self.dyn = torch.zeros(8, dtype=torch.int32, device=device)
+        self.dyn = torch.zeros(16, dtype=torch.int32, device=device)   # one length record per 16-row block tile
         self.length = 0
 
     def get_seq_length(self, layer_idx: int = 0) -> int:
@@ -78,6 +78,8 @@ class DFlashDraftModel:
         self._ws = None
         self._lm_head_cache = {}
         self._rope = None
+        # "head": dfl_attn_head on finished bf16 q/k/v rows (round 2); "fused": round-1 stage on fp32 partials
+        self.attn_impl = "head"
 
     # ------------------------------------------------------------------ weights
     def eval(self):
@@ -114,6 +116,10 @@ class DFlashDraftModel:
                 "ln1": dev(p + "input_layernorm.weight"), "ln2": dev(p + "post_attention_layernorm.weight"),
             })
             del qkv
+        # context K/V weights of ALL layers as one packed weight (tile-major layout: the k/v column tiles of
+        # each layer's packed qkv, concatenated): the context rows' K/V of every layer depend only on the
+        # context rows, so one GEMM per cycle produces them all (model/dflash.py:73-78, context half)
+        w["kv_all"] = torch.cat([lw["qkv"][c.q_dim * c.hidden_size:] for lw in w["layers"]]).contiguous()
         torch.cuda.synchronize(self.device)
         self.w = w
         self._ws = None  # row sources point at the weights: rebuild with them
@@ -149,34 +155,40 @@ class DFlashDraftModel:
             npart = max(self.ks_fc * 16 * H, self.ks_qkv * 32 * nqkv, self.ks_o * 16 * H, self.ks_down * 16 * H,
                         self.ks_kv * 16 * 2 * c.kv_dim)
             self.max_splits = 32
+            NT = 2  # block rows as up to two 16-row tiles (block sizes 17..32: the weights stream once per tile)
             self._ws = dict(
                 th_frag=torch.zeros(16 * c.fc_in, dtype=BF16, device=d),
                 ctx_frag=torch.zeros(16 * H, dtype=BF16, device=d),
-                xn_frag=torch.zeros(16 * H, dtype=BF16, device=d),
-                attn_frag=torch.zeros(16 * c.q_dim, dtype=BF16, device=d),
-                act_frag=torch.zeros(16 * I, dtype=BF16, device=d),
-                h=torch.zeros(16, H, dtype=BF16, device=d),
+                xn_frag=torch.zeros(NT, 16 * H, dtype=BF16, device=d),
+                attn_frag=torch.zeros(NT, 16 * c.q_dim, dtype=BF16, device=d),
+                act_frag=torch.zeros(NT, 16 * I, dtype=BF16, device=d),
+                h=torch.zeros(16 * NT, H, dtype=BF16, device=d),
                 ctxh=torch.zeros(16, H, dtype=BF16, device=d),
-                ss_emb=torch.zeros(16, dtype=torch.float32, device=d),
-                ss_h=torch.zeros(H, dtype=torch.float32, device=d),       # [H/16 tiles][16 rows]
+                ss_emb=torch.zeros(16 * NT, dtype=torch.float32, device=d),
+                ss_h=torch.zeros(NT, H, dtype=torch.float32, device=d),       # per tile [H/16 tiles][16 rows]
                 ss_ctx=torch.zeros(H, dtype=torch.float32, device=d),
                 q_rot=torch.zeros(c.num_attention_heads, 16, 128, dtype=BF16, device=d),
                 part=torch.zeros(npart, dtype=torch.float32, device=d),
                 attn_ws=ops.attn_fused_ws(c.num_attention_heads, c.num_key_value_heads, self.max_splits, d),
                 argmax_ws=ops.argmax_ws(d),
                 ids16=torch.zeros(16, dtype=torch.int64, device=d),
+                xq=torch.zeros(16 * NT, nqkv, dtype=BF16, device=d),
+                xc=torch.zeros(16, c.num_hidden_layers * 2 * c.kv_dim, dtype=BF16, device=d),
+                head_ws=ops.attn_head_ws(c.num_attention_heads, self.max_splits, NT, d),
             )
-            # row sources of the fused pipeline (pointers are fixed for the model's lifetime):
+            # row sources of the fused pipeline (pointers are fixed for the model's lifetime), one per block tile:
             # the GEMM that consumes a normalised activation applies the RMSNorm itself
             ws, eps, nt = self._ws, c.rms_norm_eps, H // 16
             L = self.w["layers"]
+            hs = [ws["h"][16 * t:16 * t + 16] for t in range(NT)]
             self._src = dict(
                 ctx=ops.rows_normed(ws["ctxh"], ws["ss_ctx"], nt, self.w["hidden_norm"], eps, ops.DYN_TAU),
-                ln1_first=ops.rows_normed(ws["h"], ws["ss_emb"], 1, L[0]["ln1"], eps, ops.DYN_BS),
-                ln1=[ops.rows_normed(ws["h"], ws["ss_h"], nt, lw["ln1"], eps, ops.DYN_BS) for lw in L],
-                ln2=[ops.rows_normed(ws["h"], ws["ss_h"], nt, lw["ln2"], eps, ops.DYN_BS) for lw in L],
-                final=ops.rows_normed(ws["h"], ws["ss_h"], nt, self.w["norm"], eps, ops.DYN_BS),
-                attn=ops.rows_frag(ws["attn_frag"]), act=ops.rows_frag(ws["act_frag"]),
+                ln1_first=[ops.rows_normed(hs[t], ws["ss_emb"][16 * t:], 1, L[0]["ln1"], eps, ops.DYN_BS) for t in range(NT)],
+                ln1=[[ops.rows_normed(hs[t], ws["ss_h"][t], nt, lw["ln1"], eps, ops.DYN_BS) for t in range(NT)] for lw in L],
+                ln2=[[ops.rows_normed(hs[t], ws["ss_h"][t], nt, lw["ln2"], eps, ops.DYN_BS) for t in range(NT)] for lw in L],
+                final=[ops.rows_normed(hs[t], ws["ss_h"][t], nt, self.w["norm"], eps, ops.DYN_BS) for t in range(NT)],
+                attn=[ops.rows_frag(ws["attn_frag"][t]) for t in range(NT)],
+                act=[ops.rows_frag(ws["act_frag"][t]) for t in range(NT)],
             )
         return self._ws
 
@@ -243,60 +255,97 @@ class DFlashDraftModel:
 
     def draft_block(self, cache: DFlashKVCache, *, th_rows: Optional[torch.Tensor], tau: int, bs: int, pos0: int,
                     block_ids: Optional[torch.Tensor] = None, embed: Optional[torch.Tensor] = None,
-                    noise: Optional[torch.Tensor] = None, append: bool = True) -> torch.Tensor:
+                    noise: Optional[torch.Tensor] = None, append: bool = True) -> list:
         """One draft forward over the block (model/dflash.py:166-190 for ctx <= 16 rows).
         Context rows `th_rows` [tau, fc_in] and the block (token ids + embedding table,
-        or a ready `noise` [bs, H]) -> the row source of the final-normed hidden states
-        (the lm_head GEMM applies the final RMSNorm; scratch, valid until the next call).  K/V of tau+bs rows are written at cache
-        rows S.. ; `append` advances the host length by tau (the block rows are
-        dropped again, as crop(start) does at :246)."""
+        or a ready `noise` [bs, H]) -> the row sources of the final-normed hidden states, one per
+        16-row block tile (the lm_head GEMM applies the final RMSNorm; scratch, valid until the next
+        call).  K/V of tau+bs rows are written at cache rows S.. ; `append` advances the host length
+        by tau (the block rows are dropped again, as crop(start) does at :246).
+        bs <= 32: blocks of 17..32 rows run as two 16-row tiles — every GEMM is launched once per
+        tile (the weights stream twice on such a cycle), the attention takes both query tiles."""
         c, ws, w = self.config, self._workspace(), self.w
-        if bs < 1 or bs > 16 or tau < 0 or tau > 16:
-            raise ValueError(f"bs={bs} / tau={tau}: the kernels take 1..16 block rows and 0..16 context rows")
+        if bs < 1 or bs > 32 or tau < 0 or tau > 16:
+            raise ValueError(f"bs={bs} / tau={tau}: the kernels take 1..32 block rows and 0..16 context rows")
+        head = self.attn_impl == "head"
+        if bs > 16 and not head:
+            raise ValueError("blocks of more than 16 rows need attn_impl='head'")
         S = cache.length
         if S + tau + bs > cache.max_rows:
             raise ValueError("draft KV cache too small")
         H, I = c.hidden_size, c.intermediate_size
         nqkv = c.q_dim + 2 * c.kv_dim
         cos, sin = self._rope_tab(pos0 + tau + bs + 64)
-        dyn = cache.dyn
         src = self._src
-        ops.set_dyn(dyn, S, tau, bs, pos0)
+        ops.set_dyn2(cache.dyn, S, tau, bs, pos0)
+        dyn = cache.dyn[:8]
+        tiles = [(t, cache.dyn[8 * t:8 * t + 8]) for t in range((bs + 15) // 16)]
         if tau > 0:
             # fc straight off the tap rows; hidden_norm is applied by each layer's qkv GEMM (:177)
             ops.gemm_resid(w["fc"], ops.rows_plain(th_rows, ops.DYN_TAU), H, c.fc_in, ws["ctxh"], add_residual=False,
                            ss_out=ws["ss_ctx"], dyn=dyn)
+        if head and tau > 0:   # K/V Linear outputs of the context rows, all layers, one pass over 84 MB
+            ops.gemm_resid(w["kv_all"], src["ctx"], c.num_hidden_layers * 2 * c.kv_dim, H, ws["xc"], add_residual=False,
+                           dyn=dyn)
         L = w["layers"]
         if noise is not None:  # public forward(): the caller embedded the block itself
             ws["h"][:bs].copy_(noise[:bs])
             ws["ss_emb"][:bs].copy_(noise[:bs].float().pow(2).sum(-1))
         else:
-            ops.embed_rows(embed, block_ids, ws["h"], H, ws["ss_emb"], dyn, ops.DYN_BS)
+            for t, dt in tiles:
+                ops.embed_rows(embed, block_ids[16 * t:], ws["h"][16 * t:], H, ws["ss_emb"][16 * t:], dt, ops.DYN_BS)
+        hrow = [ws["h"][16 * t:16 * t + 16] for t in range(2)]
         for i, lw in enumerate(L):
             x1 = src["ln1_first"] if i == 0 else src["ln1"][i]
-            ops.gemm_f32(lw["qkv"], src["ctx"], x1, 2, nqkv, H, self.ks_qkv, ws["part"], dyn)
-            # one launch: q/k-norm + RoPE + KV append + attention + split merge
-            ops.attn_fused(qkv=ws["part"], nsplit=self.ks_qkv, split_stride=32 * nqkv, ld=nqkv, q_col=0,
-                           k_col=c.q_dim, v_col=c.q_dim + c.kv_dim, ctx_row0=0, blk_row0=16,
-                           n_q=c.num_attention_heads, n_kv=c.num_key_value_heads, q_norm_w=lw["q_norm"],
-                           k_norm_w=lw["k_norm"], eps=c.rms_norm_eps, cos_tab=cos, sin_tab=sin, kcache=cache.k[i],
-                           vcache=cache.v[i], dyn=dyn, scale=c.head_dim ** -0.5, kv_len_max=S + tau + bs,
-                           ws=ws["attn_ws"], max_splits=self.max_splits, out_frag=ws["attn_frag"])
-            ops.gemm_resid(lw["o"], src["attn"], H, c.q_dim, ws["h"], add_residual=True, ss_out=ws["ss_h"], dyn=dyn)
-            ops.gemm_silu_mul(lw["gu"], src["ln2"][i], I, H, ws["act_frag"], dyn)
-            ops.gemm_resid(lw["down"], src["act"], H, I, ws["h"], add_residual=True, ss_out=ws["ss_h"], dyn=dyn)
+            if head:
+                for t, dt in tiles:
+                    ops.gemm_resid(lw["qkv"], x1[t], nqkv, H, ws["xq"][16 * t:], add_residual=False, dyn=dt)
+                ops.attn_head(xq=ws["xq"], q_col=0, k_col=c.q_dim, v_col=c.q_dim + c.kv_dim,
+                              xc=ws["xc"] if tau > 0 else None, ck_col=i * 2 * c.kv_dim,
+                              cv_col=i * 2 * c.kv_dim + c.kv_dim, n_q=c.num_attention_heads,
+                              n_kv=c.num_key_value_heads, q_norm_w=lw["q_norm"], k_norm_w=lw["k_norm"],
+                              eps=c.rms_norm_eps, cos_tab=cos, sin_tab=sin, kcache=cache.k[i], vcache=cache.v[i],
+                              scale=c.head_dim ** -0.5, causal=False, S=S, tau=tau, bs=bs, pos0=pos0,
+                              ws=ws["head_ws"], max_splits=self.max_splits, out_frag=ws["attn_frag"],
+                              q_tiles=len(tiles), out_tile_stride=ws["attn_frag"].stride(0))
+            else:
+                ops.gemm_f32(lw["qkv"], src["ctx"], x1[0], 2, nqkv, H, self.ks_qkv, ws["part"], dyn)
+                # one launch: q/k-norm + RoPE + KV append + attention + split merge
+                ops.attn_fused(qkv=ws["part"], nsplit=self.ks_qkv, split_stride=32 * nqkv, ld=nqkv, q_col=0,
+                               k_col=c.q_dim, v_col=c.q_dim + c.kv_dim, ctx_row0=0, blk_row0=16,
+                               n_q=c.num_attention_heads, n_kv=c.num_key_value_heads, q_norm_w=lw["q_norm"],
+                               k_norm_w=lw["k_norm"], eps=c.rms_norm_eps, cos_tab=cos, sin_tab=sin, kcache=cache.k[i],
+                               vcache=cache.v[i], dyn=dyn, scale=c.head_dim ** -0.5, kv_len_max=S + tau + bs,
+                               ws=ws["attn_ws"], max_splits=self.max_splits, out_frag=ws["attn_frag"][0])
+            for t, dt in tiles:
+                ops.gemm_resid(lw["o"], src["attn"][t], H, c.q_dim, hrow[t], add_residual=True, ss_out=ws["ss_h"][t],
+                               dyn=dt)
+            for t, dt in tiles:
+                ops.gemm_silu_mul(lw["gu"], src["ln2"][i][t], I, H, ws["act_frag"][t], dt)
+            for t, dt in tiles:
+                ops.gemm_resid(lw["down"], src["act"][t], H, I, hrow[t], add_residual=True, ss_out=ws["ss_h"][t],
+                               dyn=dt)
         if append:
             cache.length = S + tau
-        return src["final"]
+        return src["final"][:len(tiles)]
 
-    def draft_tokens(self, hid_frag: torch.Tensor, lm_head_wp: torch.Tensor, bs: int, block_ids: torch.Tensor,
+    def draft_tokens(self, hid_frag, lm_head_wp: torch.Tensor, bs: int, block_ids: torch.Tensor,
                      logits: Optional[torch.Tensor] = None, margins: Optional[torch.Tensor] = None) -> None:
         """block_ids[1:bs] <- argmax(lm_head(hidden[1:bs])) (model/dflash.py:238,245,247).
-        margins (fp32 [>= bs]): margins[j] <- top-1 minus top-2 draft logit of block slot j >= 1,
-        the reference's per-position confidence (benchmark_candidate_solutions.py:296-302)."""
+        hid_frag: what draft_block returned (one row source per 16-row tile; a single source = one tile).
+        logits (bf16 [16 * tiles, V]) / margins (fp32 [>= bs]): margins[j] <- top-1 minus top-2 draft
+        logit of block slot j >= 1, the reference's per-position confidence
+        (benchmark_candidate_solutions.py:296-302)."""
         c, ws = self.config, self._workspace()
-        ops.gemm_argmax(lm_head_wp, hid_frag, c.vocab_size, c.hidden_size, 1, bs - 1, ws["argmax_ws"], block_ids, 1,
-                        logits=logits, margins=margins)
+        srcs = hid_frag if isinstance(hid_frag, (list, tuple)) else [hid_frag]
+        for t, x in enumerate(srcs):
+            row0 = 1 if t == 0 else 0
+            nrows = min(bs - 16 * t, 16) - row0
+            if nrows <= 0:
+                continue
+            ops.gemm_argmax(lm_head_wp, x, c.vocab_size, c.hidden_size, row0, nrows, ws["argmax_ws"], block_ids,
+                            16 * t + row0, logits=None if logits is None else logits[16 * t:16 * t + 16],
+                            margins=margins)
 
     # ------------------------------------------------------------------ reference API
     @torch.inference_mode()
@@ -329,11 +378,13 @@ class DFlashDraftModel:
         frag = self.draft_block(cache, th_rows=th[head:].contiguous() if tau else None, tau=tau, bs=q_len,
                                 pos0=pos0 + head, noise=noise_embedding[0].to(BF16).contiguous())
         cache.length += q_len  # the reference's cache holds the block rows until crop()
-        del frag
         H, ws = c.hidden_size, self._workspace()
-        ops.norm_pack(norm_w=self.w["norm"], frag=ws["xn_frag"], H=H, eps=c.rms_norm_eps, resid_in=ws["h"],
-                      dyn=cache.dyn, dyn_word=ops.DYN_BS)
-        return ws["xn_frag"].view(H // 8, 16, 8).permute(1, 0, 2).reshape(16, H)[:q_len].unsqueeze(0).clone()
+        out = []
+        for t in range(len(frag)):
+            ops.norm_pack(norm_w=self.w["norm"], frag=ws["xn_frag"][t], H=H, eps=c.rms_norm_eps,
+                          resid_in=ws["h"][16 * t:16 * t + 16], dyn=cache.dyn[8 * t:8 * t + 8], dyn_word=ops.DYN_BS)
+            out.append(ws["xn_frag"][t].view(H // 8, 16, 8).permute(1, 0, 2).reshape(16, H))
+        return torch.cat(out)[:q_len].unsqueeze(0).clone()
 
     __call__ = forward
 

@@ -54,6 +54,12 @@ def set_dyn(dyn: torch.Tensor, S: int, tau: int, bs: int, pos0: int) -> None:
     check(lib().dfl_set_dyn(_p(dyn, I32, "dyn"), S, tau, bs, pos0, _stream()), "dfl_set_dyn")
 
 
+def set_dyn2(dyn: torch.Tensor, S: int, tau: int, bs: int, pos0: int) -> None:
+    """dyn int32 [>= 16]: one record per 16-row tile of a block of up to 32 rows."""
+    assert dyn.numel() >= 16
+    check(lib().dfl_set_dyn2(_p(dyn, I32, "dyn"), S, tau, bs, pos0, _stream()), "dfl_set_dyn2")
+
+
 def pack_rows(x: torch.Tensor, rows: int, out_frag: torch.Tensor, dyn=None, dyn_word=0) -> None:
     """x: [rows(+), K] bf16 with unit inner stride -> frag16 (out_frag has 16*K elements)."""
     assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == BF16 and x.is_cuda

@@ -36,7 +36,7 @@ class TargetKVCache:
         self.max_rows = int(max_rows)
         self.k = torch.zeros(n_layers, n_kv, self.max_rows, 128, dtype=BF16, device=device)
         self.v = torch.zeros_like(self.k)
-        self.dyn = torch.zeros(8, dtype=torch.int32, device=device)
+        self.dyn = torch.zeros(16, dtype=torch.int32, device=device)   # one length record per 16-row block tile
         self.length = 0
 
     def get_seq_length(self, layer_idx: int = 0) -> int:
@@ -119,20 +119,24 @@ class NativeTarget:
         self.ks_down = ops.pick_ksplit(self.H, self.I, 1)
         npart = max(self.ks_qkv * 16 * self.nqkv, self.ks_o * 16 * self.H, self.ks_down * 16 * self.H)
         z = lambda *s, dt=BF16: torch.zeros(*s, dtype=dt, device=dev)  # noqa: E731
-        self.ws = dict(attn=z(16 * self.q_dim), act=z(16 * self.I), h=z(16, self.H),
-                       ss_emb=z(16, dt=torch.float32), ss_h=z(self.H, dt=torch.float32),
+        NT = 2  # block rows as up to two 16-row tiles (blocks of 17..32 rows: one GEMM launch per tile)
+        self.ws = dict(attn=z(NT, 16 * self.q_dim), act=z(NT, 16 * self.I), h=z(16 * NT, self.H),
+                       ss_emb=z(16 * NT, dt=torch.float32), ss_h=z(NT, self.H, dt=torch.float32),
                        q=z(self.n_q, 16, 128), part=z(npart, dt=torch.float32),
                        attn_ws=ops.attn_fused_ws(self.n_q, self.n_kv, max_splits, dev), argmax_ws=ops.argmax_ws(dev),
-                       xq=z(16, self.nqkv), head_ws=ops.attn_head_ws(self.n_q, max_splits, 1, dev),
-                       post=torch.zeros(16, dtype=torch.int64, device=dev))
+                       xq=z(16 * NT, self.nqkv), head_ws=ops.attn_head_ws(self.n_q, max_splits, NT, dev),
+                       post=torch.zeros(16 * NT, dtype=torch.int64, device=dev))
         ws, nt = self.ws, self.H // 16
-        # row sources: the consuming GEMM applies the RMSNorm itself (no norm launches)
+        hs = [ws["h"][16 * t:16 * t + 16] for t in range(NT)]
+        # row sources, one per tile: the consuming GEMM applies the RMSNorm itself (no norm launches)
         self.src = dict(
-            ln1=[ops.rows_normed(ws["h"], ws["ss_emb"] if i == 0 else ws["ss_h"], 1 if i == 0 else nt, lw["ln1"],
-                                 self.eps, ops.DYN_BS) for i, lw in enumerate(self.layers)],
-            ln2=[ops.rows_normed(ws["h"], ws["ss_h"], nt, lw["ln2"], self.eps, ops.DYN_BS) for lw in self.layers],
-            final=ops.rows_normed(ws["h"], ws["ss_h"], nt, self.norm, self.eps, ops.DYN_BS),
-            attn=ops.rows_frag(ws["attn"]), act=ops.rows_frag(ws["act"]))
+            ln1=[[ops.rows_normed(hs[t], ws["ss_emb"][16 * t:] if i == 0 else ws["ss_h"][t], 1 if i == 0 else nt,
+                                  lw["ln1"], self.eps, ops.DYN_BS) for t in range(NT)]
+                 for i, lw in enumerate(self.layers)],
+            ln2=[[ops.rows_normed(hs[t], ws["ss_h"][t], nt, lw["ln2"], self.eps, ops.DYN_BS) for t in range(NT)]
+                 for lw in self.layers],
+            final=[ops.rows_normed(hs[t], ws["ss_h"][t], nt, self.norm, self.eps, ops.DYN_BS) for t in range(NT)],
+            attn=[ops.rows_frag(ws["attn"][t]) for t in range(NT)], act=[ops.rows_frag(ws["act"][t]) for t in range(NT)])
         self._rope = None
         self._taps = {}
         torch.cuda.synchronize(dev)
@@ -186,22 +190,27 @@ class NativeTarget:
     def verify(self, block_ids: torch.Tensor, start: int, cache: TargetKVCache, *, tap_layers: Sequence[int] = (),
                temperature: float = 0.0, logits_out: Optional[torch.Tensor] = None,
                taps_out: Optional[torch.Tensor] = None):
-        """block_ids int64 [bs] at positions start..start+bs-1 (cache rows alike).
-        Returns (posterior ids int64 [1, bs], taps bf16 [16, len(tap_layers)*H] or None).
+        """block_ids int64 [bs] at positions start..start+bs-1 (cache rows alike), bs <= 32.
+        Returns (posterior ids int64 [1, bs], taps bf16 [32, len(tap_layers)*H] or None).
         K/V of all bs rows are written; the caller crops to what it accepts.
-        taps_out: the caller's own [16, len(tap_layers)*H] buffer (a decode session keeps the
-        rows until its next draft; sessions interleaved on one target must not share one)."""
+        taps_out: the caller's own [32, len(tap_layers)*H] buffer (a decode session keeps the
+        rows until its next draft; sessions interleaved on one target must not share one).
+        logits_out: bf16 [16 * tiles, V].  Blocks of 17..32 rows run as two 16-row tiles: one
+        launch per tile of every GEMM, both query tiles in the attention launch."""
         bs = block_ids.numel()
-        if bs < 1 or bs > 16:
-            raise ValueError("verify takes 1..16 block rows")
+        if bs < 1 or bs > 32:
+            raise ValueError("verify takes 1..32 block rows")
+        if bs > 16 and self.attn_impl != "head":
+            raise ValueError("blocks of more than 16 rows need attn_impl='head'")
         if start + bs > cache.max_rows:
             raise ValueError("target KV cache too small")
         ws, H = self.ws, self.H
         if self.lm_wp is None:
             self.lm_wp = ops.pack_weight(self.lm_head.weight.detach().to(BF16).contiguous())
         cos, sin = self._rope_tab(start + bs + 64)
-        dyn = cache.dyn
-        ops.set_dyn(dyn, start, 0, bs, start)
+        ops.set_dyn2(cache.dyn, start, 0, bs, start)
+        dyn = cache.dyn[:8]
+        tiles = [(t, cache.dyn[8 * t:8 * t + 8]) for t in range((bs + 15) // 16)]
         taps = None
         tap_layers = list(tap_layers)
         if tap_layers:
@@ -209,53 +218,61 @@ class NativeTarget:
                 raise NotImplementedError("tapping the last layer (post-norm state) is not supported")
             key = len(tap_layers)
             if taps_out is not None:
-                if taps_out.shape != (16, key * H) or taps_out.dtype != BF16 or not taps_out.is_contiguous():
-                    raise ValueError("taps_out must be a contiguous bf16 [16, len(tap_layers)*H] tensor")
+                if taps_out.shape != (32, key * H) or taps_out.dtype != BF16 or not taps_out.is_contiguous():
+                    raise ValueError("taps_out must be a contiguous bf16 [32, len(tap_layers)*H] tensor")
                 taps = taps_out
             else:
                 if key not in self._taps:
-                    self._taps[key] = torch.zeros(16, key * H, dtype=BF16, device=self._dev)
+                    self._taps[key] = torch.zeros(32, key * H, dtype=BF16, device=self._dev)
                 taps = self._taps[key]
         Ls, src = self.layers, self.src
-        ops.embed_rows(self.embed, block_ids, ws["h"], H, ws["ss_emb"], dyn, ops.DYN_BS)
+        hrow = [ws["h"][16 * t:16 * t + 16] for t in range(2)]
+        for t, dt in tiles:
+            ops.embed_rows(self.embed, block_ids[16 * t:], hrow[t], H, ws["ss_emb"][16 * t:], dt, ops.DYN_BS)
         for i, lw in enumerate(Ls):
             if self.attn_impl == "head":
                 # q/k/v as finished bf16 Linear outputs (no K split: 192 workgroups x 2 column tiles), then
                 # one launch: q/k-norm + RoPE + append + causal attention + split merge
-                ops.gemm_resid(lw["qkv"], src["ln1"][i], self.nqkv, H, ws["xq"], add_residual=False, dyn=dyn)
+                for t, dt in tiles:
+                    ops.gemm_resid(lw["qkv"], src["ln1"][i][t], self.nqkv, H, ws["xq"][16 * t:], add_residual=False,
+                                   dyn=dt)
                 ops.attn_head(xq=ws["xq"], q_col=0, k_col=self.q_dim, v_col=self.q_dim + self.kv_dim, n_q=self.n_q,
                               n_kv=self.n_kv, q_norm_w=lw["q_norm"], k_norm_w=lw["k_norm"], eps=self.eps, cos_tab=cos,
                               sin_tab=sin, kcache=cache.k[i], vcache=cache.v[i], scale=128 ** -0.5, causal=True,
                               S=start, tau=0, bs=bs, pos0=start, ws=ws["head_ws"], max_splits=self.max_splits,
-                              out_frag=ws["attn"])
+                              out_frag=ws["attn"], q_tiles=len(tiles), out_tile_stride=ws["attn"].stride(0))
             else:
-                ops.gemm_f32(lw["qkv"], src["ln1"][i], None, 1, self.nqkv, H, self.ks_qkv, ws["part"], dyn)
+                ops.gemm_f32(lw["qkv"], src["ln1"][i][0], None, 1, self.nqkv, H, self.ks_qkv, ws["part"], dyn)
                 ops.attn_fused(qkv=ws["part"], nsplit=self.ks_qkv, split_stride=16 * self.nqkv, ld=self.nqkv, q_col=0,
                                k_col=self.q_dim, v_col=self.q_dim + self.kv_dim, ctx_row0=0, blk_row0=0, n_q=self.n_q,
                                n_kv=self.n_kv, q_norm_w=lw["q_norm"], k_norm_w=lw["k_norm"], eps=self.eps,
                                cos_tab=cos, sin_tab=sin, kcache=cache.k[i], vcache=cache.v[i], dyn=dyn,
                                scale=128 ** -0.5, kv_len_max=start + bs, ws=ws["attn_ws"],
-                               max_splits=self.max_splits, out_frag=ws["attn"], causal=True)
-            ops.gemm_resid(lw["o"], src["attn"], H, self.q_dim, ws["h"], add_residual=True, ss_out=ws["ss_h"],
-                           dyn=dyn)
-            ops.gemm_silu_mul(lw["gu"], src["ln2"][i], self.I, H, ws["act"], dyn)
+                               max_splits=self.max_splits, out_frag=ws["attn"][0], causal=True)
+            for t, dt in tiles:
+                ops.gemm_resid(lw["o"], src["attn"][t], H, self.q_dim, hrow[t], add_residual=True,
+                               ss_out=ws["ss_h"][t], dyn=dt)
+            for t, dt in tiles:
+                ops.gemm_silu_mul(lw["gu"], src["ln2"][i][t], self.I, H, ws["act"][t], dt)
             # every slot j with tap_layers[j] == i: build_target_layer_ids repeats layers for shallow
             # targets and the reference concatenates the same state twice (model/utils.py:16-25)
             sl = [j for j, l in enumerate(tap_layers) if l == i]
-            tap = taps[:, sl[0] * H:(sl[0] + 1) * H] if sl else None
-            ops.gemm_resid(lw["down"], src["act"], H, self.I, ws["h"], add_residual=True, ss_out=ws["ss_h"], tap=tap,
-                           dyn=dyn)
+            for t, dt in tiles:
+                tap = taps[16 * t:16 * t + 16, sl[0] * H:(sl[0] + 1) * H] if sl else None
+                ops.gemm_resid(lw["down"], src["act"][t], H, self.I, hrow[t], add_residual=True, ss_out=ws["ss_h"][t],
+                               tap=tap, dyn=dt)
             for j in sl[1:]:
-                taps[:, j * H:(j + 1) * H].copy_(tap)
+                taps[:, j * H:(j + 1) * H].copy_(taps[:, sl[0] * H:(sl[0] + 1) * H])
         post = ws["post"]
+        logits = logits_out
+        if temperature >= 1e-5:
+            logits = torch.empty(16 * len(tiles), self.V, dtype=BF16, device=self._dev)
+        for t, dt in tiles:
+            ops.gemm_argmax(self.lm_wp, src["final"][t], self.V, H, 0, min(16, bs - 16 * t), ws["argmax_ws"], post, 16 * t,
+                            dyn=dt, logits=None if logits is None else logits[16 * t:16 * t + 16])
         if temperature < 1e-5:
-            ops.gemm_argmax(self.lm_wp, src["final"], self.V, H, 0, bs, ws["argmax_ws"], post, 0, dyn=dyn,
-                            logits=logits_out)
             posterior = post[:bs].unsqueeze(0)
         else:
-            logits = torch.empty(16, self.V, dtype=BF16, device=self._dev)
-            ops.gemm_argmax(self.lm_wp, src["final"], self.V, H, 0, bs, ws["argmax_ws"], post, 0, dyn=dyn,
-                            logits=logits)
             posterior = sample(logits[:bs].unsqueeze(0), temperature)
         cache.length = start + bs
         return posterior, taps

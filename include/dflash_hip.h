@@ -93,6 +93,11 @@ int dfl_pack_weight_gateup(const void *gate, const void *up, void *wp, int I, in
 
 /* dyn <- {S, tau, bs, pos0, start=pos0+tau, stop=0, cycle=0}. */
 int dfl_set_dyn(int32_t *dyn, int S, int tau, int bs, int pos0, void *stream);
+/* Blocks of 17..32 rows (results.md:11-16 sweeps 20 and 24; benchmark_dynamic_schedule.py:44-51 takes any
+ * candidate >= 2) run as TWO 16-row tiles: every GEMM / embed launch is issued once per tile on rows 16 t ..
+ * with the tile's own record.  dyn holds 2 x DFL_DYN_WORDS ints; record t gets
+ * {S, clamp(tau - 16 t, 0, 16), clamp(bs - 16 t, 0, 16), pos0, start, 0, 0}. */
+int dfl_set_dyn2(int32_t *dyn, int S, int tau, int bs, int pos0, void *stream);
 
 /* rows x K bf16 (row stride ldx elements) -> frag16; rows beyond n_valid zeroed.
  * n_valid = dyn[dyn_word] if dyn != NULL else rows.  Used for the target taps

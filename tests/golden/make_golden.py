@@ -17,6 +17,7 @@ Fixtures (SURVEY.md §8c list):
   G5 scheduler.json            EWMAPerformanceScheduler decision traces
   G6 sample_t.npz              sample(logits, 0.7) under torch.manual_seed
   G7 harness.json              summarize_mode / summarize_profile of benchmark.py
+  G8 draft_forward_*_wide.npz, e2e_wide.json   block sizes 17..32 (forward vectors; loop runs at 20 / 24 / 32, policy)
 """
 import json
 import os
@@ -312,7 +313,64 @@ def gen_harness():
     print("G7 done")
 
 
+# ---------------------------------------------------------------- G8: blocks wider than 16 rows
+def gen_wide():
+    """Block sizes 17..32 (results.md:11-16 sweeps 20 and 24; the scheduler takes any candidate >= 2,
+    benchmark_dynamic_schedule.py:44-51): G1-style forward vectors and G4-style loop runs."""
+    tiny = H.tiny_cfg()
+    # (bs, tau_next): context rows of the next cycle go up to the block size
+    gen_draft_forward("tiny_bf16_sdpa_wide", tiny, torch.bfloat16, "sdpa", 40,
+                      [(24, 5), (20, 20), (32, 17), (17, 2), (24, 24), (16, 9)], 103)
+    cfg = tiny
+    res = {}
+    ref_bench.cuda_time = time.perf_counter
+    clock = {"t": 0.0}
+
+    def fake_time():
+        clock["t"] += 1e-3
+        return clock["t"]
+    ref_dyn.cuda_time = fake_time
+    dtype, attn = torch.bfloat16, "sdpa"
+    sd = H.draft_weights(cfg, dtype=dtype)
+    model = ref_draft(cfg, sd, dtype, attn)
+    prompt = torch.randint(0, 2000, (1, 37), generator=torch.Generator().manual_seed(21))
+
+    def scripted(plan_seed, tape_seed, total, plan_bs):
+        base = H.tiny_target(dtype=dtype, attn_impl=attn)
+        tape = H.make_tape(total + 64, cfg.vocab_size, tape_seed, forbid=(cfg.mask_token_id,))
+        return H.ScriptedTarget(base, tape, H.make_plan(64, plan_bs, plan_seed))
+
+    for key, bs, mnt in (("gen_bs20", 20, 90), ("gen_bs24", 24, 100), ("gen_bs32", 32, 120)):
+        tgt = scripted(16, 17, 37 + mnt, bs)
+        r = ref_bench.dflash_generate(model, tgt, prompt, cfg.mask_token_id, mnt, bs, None, 0.0,
+                                      collect_profile=False, draft_steps=1)
+        res[f"bf16_sdpa/{key}"] = {"prompt": prompt[0].tolist(), "max_new_tokens": mnt, "block_size": bs,
+                                   "draft_steps": 1, "ids": r.output_ids[0].tolist(),
+                                   "acceptance_lengths": [int(a) for a in r.acceptance_lengths],
+                                   "num_output_tokens": int(r.num_output_tokens), "plan_seed": 16, "tape_seed": 17,
+                                   "plan_bs": bs}
+    sched = ref_dyn.EWMAPerformanceScheduler(
+        candidates=[12, 20, 24], scheduler_mode="ewma", warmup_cycles=6, ewma_alpha=0.25, switch_margin=0.03,
+        required_streak=2, cooldown_cycles=2, probe_interval=5, low_accept_threshold=0.2, low_accept_streak=3,
+        adl_rho=0.3, adl_delta=1.0, adl_k_min=8, adl_k_max=24, adl_neighborhood=4)
+    tgt = scripted(18, 19, 37 + 150, 24)
+    r = ref_dyn.dflash_generate_policy(model=model, target=tgt, input_ids=prompt, mask_token_id=cfg.mask_token_id,
+                                       max_new_tokens=150, stop_token_ids=None, temperature=0.0, scheduler=sched)
+    res["bf16_sdpa/policy_wide"] = {"prompt": prompt[0].tolist(), "max_new_tokens": 150, "stop_token_ids": None,
+                                    "ids": r.output_ids[0].tolist(),
+                                    "acceptance_lengths": [int(a) for a in r.acceptance_lengths],
+                                    "used_block_sizes": [int(b) for b in r.used_block_sizes],
+                                    "chosen_block_sizes": [int(t["chosen_block_size"]) for t in r.cycle_trace],
+                                    "l_gen": [float(t["l_gen"]) for t in r.cycle_trace],
+                                    "plan_seed": 18, "tape_seed": 19, "plan_bs": 24, "candidates": [12, 20, 24]}
+    json.dump(res, open(os.path.join(HERE, "e2e_wide.json"), "w"))
+    print("G8 done")
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["wide"]:     # later additions are generated alone: the round-1 fixtures stay byte-identical
+        gen_wide()
+        sys.exit(0)
     tiny, mid = H.tiny_cfg(), H.mid_cfg()
     # (bs, tau_next): block size this cycle, tokens committed after it (= next cycle's ctx rows)
     steps = [(16, 1), (16, 7), (16, 16), (12, 3), (8, 8), (16, 2)]
@@ -326,3 +384,4 @@ if __name__ == "__main__":
     gen_scheduler()
     gen_sample_t()
     gen_harness()
+    gen_wide()

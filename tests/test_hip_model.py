@@ -31,7 +31,8 @@ def make_model(cfg, seed=3):
 # unit-scale outputs; we require max-abs <= 4e-2 of the output scale against the bf16
 # golden and a mean-abs an order of magnitude below that.
 @pytest.mark.parametrize("tag,cfgf", [("tiny_bf16_eager", H.tiny_cfg), ("tiny_bf16_sdpa", H.tiny_cfg),
-                                      ("mid_bf16_sdpa", H.mid_cfg)])
+                                      ("mid_bf16_sdpa", H.mid_cfg),
+                                      ("tiny_bf16_sdpa_wide", H.tiny_cfg)])   # blocks of 17..32 rows (golden G8)
 def test_forward_matches_reference_vectors(tag, cfgf):
     z = np.load(os.path.join(H.GOLDEN, f"draft_forward_{tag}.npz"))
     cfg = cfgf()
@@ -229,7 +230,7 @@ def test_native_verify_matches_hf_forward():
     assert torch.equal(post[0], torch.argmax(logits, dim=-1))
     H.assert_ids_match_where_safe("tiny verify ids", post[0], rl)
     for j, l in enumerate(taps):
-        H.assert_close(f"tiny verify tap {l}", th[:, j * 512:(j + 1) * 512], ref.hidden_states[l + 1][0])
+        H.assert_close(f"tiny verify tap {l}", th[:16, j * 512:(j + 1) * 512], ref.hidden_states[l + 1][0])
     for li in (0, 5):
         H.assert_close(f"tiny verify K layer {li}", cache.k[li][:, :61], rc.layers[li].keys[0], max_rel=H.KV_MAX_REL)
         H.assert_close(f"tiny verify V layer {li}", cache.v[li][:, :61], rc.layers[li].values[0], max_rel=H.KV_MAX_REL)
@@ -418,7 +419,7 @@ def test_qwen3_4b_geometry_matches_oracle():
               output_hidden_states=True)
     H.assert_close("4B-geometry verify logits", logits, refo.logits[0])
     for j, li in enumerate((0, 2)):
-        H.assert_close(f"4B-geometry verify tap {li}", taps[:, j * 640:(j + 1) * 640], refo.hidden_states[li + 1][0])
+        H.assert_close(f"4B-geometry verify tap {li}", taps[:16, j * 640:(j + 1) * 640], refo.hidden_states[li + 1][0])
 
 
 def test_full_size_draft_cycle_matches_oracle():
@@ -518,3 +519,114 @@ def test_harness_options_on_native_target():
                                 max_new_tokens=n_new, stop_token_ids=None, temperature=0.7, scheduler=sched)
     assert rp.output_ids[0].tolist() == want          # margin ~70: the T = 0.7 posterior draw is the argmax
     assert set(rp.used_block_sizes) <= {8, 12, 16} | set(range(1, 17)) and len(rp.cycle_trace) == len(rp.acceptance_lengths)
+
+
+# ------------------------------------------------------------------ blocks of 17..32 rows (golden G8)
+WIDE = json.load(open(os.path.join(H.GOLDEN, "e2e_wide.json")))
+
+
+def _scripted_wide(g, cfg):
+    base = H.tiny_target(dtype=BF16, device=dev())
+    total = len(g["prompt"]) + g["max_new_tokens"]
+    tape = H.make_tape(total + 64, cfg.vocab_size, g["tape_seed"], forbid=(cfg.mask_token_id,))
+    t = H.ScriptedTarget(base, tape, H.make_plan(64, g["plan_bs"], g["plan_seed"]))
+    t.script_lm_head = False
+    return t
+
+
+def test_wide_blocks_match_reference_ids():
+    """Block sizes 20 / 24 / 32 (results.md:11-16, run_block_sweep.sh) and a {12, 20, 24} schedule
+    (benchmark_dynamic_schedule.py:44-51 takes any candidate >= 2): committed ids, acceptance lengths (up to 32)
+    and used block sizes equal the reference's runs."""
+    from dflash_amd import dflash_generate, dflash_generate_policy
+    cfg = H.tiny_cfg()
+    m = make_model(cfg)
+    for key in ("gen_bs20", "gen_bs24", "gen_bs32"):
+        g = WIDE[f"bf16_sdpa/{key}"]
+        tgt = _scripted_wide(g, cfg)
+        r = dflash_generate(m, tgt, torch.tensor([g["prompt"]], device=dev()), cfg.mask_token_id,
+                            g["max_new_tokens"], g["block_size"], None, 0.0, draft_token_hook=tgt.draft_token_hook)
+        assert r.output_ids[0].tolist() == g["ids"], key
+        assert r.acceptance_lengths == g["acceptance_lengths"], key
+        assert max(r.acceptance_lengths) > 16
+    g = WIDE["bf16_sdpa/policy_wide"]
+    tgt = _scripted_wide(g, cfg)
+    sch = _Replay(g["chosen_block_sizes"], g["candidates"])
+    r = dflash_generate_policy(model=m, target=tgt, input_ids=torch.tensor([g["prompt"]], device=dev()),
+                               mask_token_id=cfg.mask_token_id, max_new_tokens=g["max_new_tokens"],
+                               stop_token_ids=None, temperature=0.0, scheduler=sch,
+                               draft_token_hook=tgt.draft_token_hook)
+    assert r.output_ids[0].tolist() == g["ids"]
+    assert r.acceptance_lengths == g["acceptance_lengths"] and r.used_block_sizes == g["used_block_sizes"]
+    with pytest.raises(ValueError):      # 33 rows: rejected before the prefill runs
+        dflash_generate(m, tgt, torch.tensor([g["prompt"]], device=dev()), cfg.mask_token_id, 8, 33, None, 0.0)
+
+
+@pytest.mark.parametrize("bs", [17, 24, 32])
+def test_native_verify_wide_block_matches_hf_forward(bs):
+    """The native verify on two 16-row tiles (one launch per tile of every GEMM, both query tiles in the
+    attention launch) against the HF forward: logits of all bs rows, taps, appended K/V."""
+    from transformers import DynamicCache
+    from dflash_amd import NativeTarget
+    hf = _tiny_hf()
+    nt = NativeTarget(hf)
+    g = torch.Generator().manual_seed(40 + bs)
+    P = 45
+    prompt = torch.randint(0, 2000, (1, P), generator=g).to(dev())
+    block = torch.randint(0, 2000, (1, bs), generator=g).to(dev())
+    taps = [1, 3]
+    cache = nt.new_cache(128)
+    nt.prefill(prompt, cache)
+    logits = torch.zeros(32, 2048, dtype=BF16, device=dev())
+    post, th = nt.verify(block[0], P, cache, tap_layers=taps, logits_out=logits)
+    rc = DynamicCache()
+    with torch.inference_mode():
+        hf(prompt, past_key_values=rc, use_cache=True)
+        ref = hf(block, position_ids=torch.arange(P, P + bs, device=dev())[None], past_key_values=rc, use_cache=True,
+                 output_hidden_states=True)
+    rl = ref.logits[0].float()
+    H.assert_close(f"bs {bs} verify logits", logits[:bs], rl)
+    assert post.shape == (1, bs) and torch.equal(post[0], torch.argmax(logits[:bs], dim=-1))
+    H.assert_ids_match_where_safe(f"bs {bs} verify ids", post[0], rl)
+    for j, l in enumerate(taps):
+        H.assert_close(f"bs {bs} verify tap {l}", th[:bs, j * 512:(j + 1) * 512], ref.hidden_states[l + 1][0])
+    for li in (0, 5):
+        H.assert_close(f"bs {bs} verify K layer {li}", cache.k[li][:, :P + bs], rc.layers[li].keys[0], max_rel=H.KV_MAX_REL)
+        H.assert_close(f"bs {bs} verify V layer {li}", cache.v[li][:, :P + bs], rc.layers[li].values[0], max_rel=H.KV_MAX_REL)
+    assert cache.get_seq_length() == P + bs
+
+
+def test_native_target_wide_blocks_lossless_walk():
+    """bs = 24 and a {12, 20, 24} schedule end to end on the NATIVE verify: the committed ids are the target's
+    closed-form greedy walk, with scripted acceptance lengths up to 24."""
+    from dflash_amd import EWMAPerformanceScheduler, NativeTarget, dflash_generate, dflash_generate_policy
+    from dflash_amd.synthetic import greedy_walk, impose_greedy_walk
+    cfg = H.tiny_cfg()
+    m = make_model(cfg)
+    hf = _tiny_hf()
+    perm = impose_greedy_walk(hf, seed=5)
+    nt = NativeTarget(hf)
+    prompt = torch.randint(0, 2000, (1, 33), generator=torch.Generator().manual_seed(4)).to(dev())
+    n_new = 120
+    G = greedy_walk(perm, prompt, n_new + 64).to(dev())
+    plan = H.make_plan(64, 24, 23)
+
+    def hook(blk, start, call):
+        k = min(plan[call], blk.shape[1] - 1)
+        blk[0, 1:k + 1] = G[start + 1:start + k + 1]
+        if k + 1 < blk.shape[1]:
+            w = G[start + k + 1]
+            blk[0, k + 1] = torch.where(blk[0, k + 1] == w, (w + 1) % 2000, blk[0, k + 1])
+
+    r = dflash_generate(m, nt, prompt, cfg.mask_token_id, n_new, 24, None, 0.0, draft_token_hook=hook)
+    assert r.output_ids[0].tolist() == G[:33 + n_new].tolist()
+    assert max(r.acceptance_lengths) == 24 and r.acceptance_lengths[:4] == [1, 24, 2, 23]
+    sched = EWMAPerformanceScheduler(candidates=[12, 20, 24], scheduler_mode="ewma", warmup_cycles=3, ewma_alpha=0.25,
+                                     switch_margin=0.03, required_streak=2, cooldown_cycles=2, probe_interval=5,
+                                     low_accept_threshold=0.2, low_accept_streak=3, adl_rho=0.3, adl_delta=1.0,
+                                     adl_k_min=8, adl_k_max=24, adl_neighborhood=4)
+    rp = dflash_generate_policy(model=m, target=nt, input_ids=prompt, mask_token_id=cfg.mask_token_id,
+                                max_new_tokens=n_new, stop_token_ids=None, temperature=0.0, scheduler=sched,
+                                draft_token_hook=hook)
+    assert rp.output_ids[0].tolist() == G[:33 + n_new].tolist()
+    assert set(rp.used_block_sizes) & {20, 24}

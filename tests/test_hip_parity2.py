@@ -376,7 +376,7 @@ def test_repeated_target_layer_ids_fill_every_tap_slot():
         ref = hf(block, position_ids=torch.arange(37, 53, device=dev())[None], past_key_values=rc, use_cache=True,
                  output_hidden_states=True)
     want = extract_context_feature(ref.hidden_states, ids)[0]
-    H.assert_close("repeated taps, single request", th, want)
+    H.assert_close("repeated taps, single request", th[:16], want)
     assert torch.equal(th[:, 512:1024], th[:, 1024:1536]) and torch.equal(th[:, 512:1024], th[:, 1536:2048])
     # batched verify: same rows in every slot
     from dflash_amd import DFlashDraftModel
