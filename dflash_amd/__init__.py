@@ -15,7 +15,8 @@ from .scheduler import EWMAPerformanceScheduler
 from .model import DFlashDraftModel, DFlashKVCache
 from .generate import dflash_generate, dflash_generate_policy
 from .target import NativeTarget
+from .candidates import dflash_generate_candidate_solutions
 
 __all__ = ["DFlashConfig", "DFlashDraftModel", "DFlashKVCache", "EWMAPerformanceScheduler",
            "build_target_layer_ids", "extract_context_feature", "sample", "dflash_generate",
-           "dflash_generate_policy", "NativeTarget"]
+           "dflash_generate_policy", "NativeTarget", "dflash_generate_candidate_solutions"]

@@ -60,6 +60,14 @@ struct HeadAttnArgs {
   float *ml_part;  // [ns][n_q][QT*16][2]
   int *tickets;    // [n_q]
   int ns_old;      // splits over the cached (old) keys; split ns_old owns the new rows
+  // candidate blocks (grid.z = candidate, SURVEY.md §8f-4: several drafts of one block verified against ONE cached
+  // prefix): candidate c reads its block rows at xq + c * xq_cand_stride, writes its frag16 output at
+  // out_frag + c * out_cand_stride, its partials / tickets at + c * ws_cand_stride floats, and its NEW K/V rows
+  // not into the cache but into kv_out rows [0, bs): [c][n_kv][out_rows][128] — the caller copies the winner's.
+  int64_t xq_cand_stride, out_cand_stride, ws_cand_stride;
+  bf16_t *k_out, *v_out;   // null: the new rows go to the cache at rows S + rel
+  int64_t kv_out_cand_stride;
+  int out_rows;
 };
 
 // 64-lane butterflies on VALU: v_permlane16_swap / v_permlane32_swap (gfx950) instead of
@@ -222,6 +230,17 @@ __global__ __launch_bounds__(512) void k_attn_head(HeadAttnArgs a) {
   const int n_new = tau + bs;  // <= 64
   const int qi = l & 15, g = l >> 4;
   HSTAMP(0);
+  // candidate c of a multi-candidate verify (grid.z; 0 otherwise): plain locals, the argument block stays untouched
+  const int cand = blockIdx.z;
+  const bf16_t *const xq = a.xq + cand * a.xq_cand_stride;
+  bf16x8 *const out_frag = a.out_frag + cand * a.out_cand_stride;
+  float *const o_part = a.o_part + cand * a.ws_cand_stride;
+  float *const ml_part = a.ml_part + cand * a.ws_cand_stride;
+  int *const tickets = a.tickets + cand * a.ws_cand_stride;
+  bf16_t *const k_new = a.k_out ? a.k_out + cand * a.kv_out_cand_stride : a.kc;
+  bf16_t *const v_new = a.k_out ? a.v_out + cand * a.kv_out_cand_stride : a.vc;
+  const int new_rows_cap = a.k_out ? a.out_rows : a.cache_rows;
+  const int new_row0 = a.k_out ? 0 : S;
 
   const bf16_t *kbase = a.kc + (int64_t)kvh * a.cache_rows * 128;
   const bf16_t *vbase = a.vc + (int64_t)kvh * a.cache_rows * 128;
@@ -263,9 +282,9 @@ __global__ __launch_bounds__(512) void k_attn_head(HeadAttnArgs a) {
   const int jq = 4 * w + g;  // this 16-lane group's q row (QT = 1: waves 0..3 hold rows, the others a dummy)
   RopeLoads<1> qld;
   {
-    const bf16_t *src[1] = {jq < bs ? a.xq + (int64_t)jq * a.ldq + a.q_col + head * 128 : nullptr};
+    const bf16_t *src[1] = {jq < bs ? xq + (int64_t)jq * a.ldq + a.q_col + head * 128 : nullptr};
     const int pos[1] = {pos0 + tau + jq};
-    rope_issue<1>(src, pos, a.q_w, a.cos_tab, a.sin_tab, a.max_pos, a.xq, l, qld);
+    rope_issue<1>(src, pos, a.q_w, a.cos_tab, a.sin_tab, a.max_pos, xq, l, qld);
   }
   // (compiler fences: without them hipcc hoists the K/V burst above the q loads and sinks the norm-weight load
   // into a branch of the arithmetic, and the q rows wait for the whole burst after all)
@@ -307,13 +326,13 @@ __global__ __launch_bounds__(512) void k_attn_head(HeadAttnArgs a) {
         // addresses plus a per-lane global load with vmcnt(0) — four dependent round trips in this prologue)
         const int vsel = isv[p] ? 1 : 0;
         const bf16_t *row = rel[p] < tau ? a.xc + (int64_t)rel[p] * a.ldc + a.ck_col + vsel * (a.cv_col - a.ck_col)
-                                         : a.xq + (int64_t)(rel[p] - tau) * a.ldq + a.k_col + vsel * (a.v_col - a.k_col);
+                                         : xq + (int64_t)(rel[p] - tau) * a.ldq + a.k_col + vsel * (a.v_col - a.k_col);
         src[p] = ok ? row + kvh * 128 : nullptr;
         pos[p] = pos0 + rel[p];
         rp[p] = !isv[p];
       }
       RopeLoads<NP> kld;
-      rope_issue<NP>(src, pos, a.k_w, a.cos_tab, a.sin_tab, a.max_pos, a.xq, l, kld);
+      rope_issue<NP>(src, pos, a.k_w, a.cos_tab, a.sin_tab, a.max_pos, xq, l, kld);
       asm volatile("" ::: "memory");
       finish_q();
       rope_finish<NP>(kld, rp, a.k_w != nullptr, a.eps, l, ov);
@@ -322,9 +341,9 @@ __global__ __launch_bounds__(512) void k_attn_head(HeadAttnArgs a) {
         if (src[p]) {
           const int jt = rel[p] >> 5, r = rel[p] & 31;
           *reinterpret_cast<bf16x8 *>((isv[p] ? new_v + jt * 8192 + v_swz(r, qi) : new_k + jt * 8192 + k_swz(r, qi))) = ov[p];
-          const int crow = S + rel[p];
-          if (hh == 0 && crow < a.cache_rows)
-            *reinterpret_cast<bf16x8 *>((isv[p] ? a.vc : a.kc) + ((int64_t)kvh * a.cache_rows + crow) * 128 + qi * 8) = ov[p];
+          const int crow = new_row0 + rel[p];
+          if (hh == 0 && crow < new_rows_cap)
+            *reinterpret_cast<bf16x8 *>((isv[p] ? v_new : k_new) + ((int64_t)kvh * new_rows_cap + crow) * 128 + qi * 8) = ov[p];
         }
     };
     if (2 * n_new <= 32)
@@ -505,7 +524,7 @@ __global__ __launch_bounds__(512) void k_attn_head(HeadAttnArgs a) {
     bf16x8 r;
 #pragma unroll
     for (int j = 0; j < 8; ++j) r[j] = f2bf(v[j] * inv);
-    a.out_frag[qt * a.out_tile_stride + (head * 16 + dg) * 16 + q] = r;
+    out_frag[qt * a.out_tile_stride + (head * 16 + dg) * 16 + q] = r;
   };
   HSTAMP(4);
   if (ns == 1) {
@@ -517,9 +536,9 @@ __global__ __launch_bounds__(512) void k_attn_head(HeadAttnArgs a) {
   const size_t item_row = (size_t)head * (QT * 16) + qt * 16 + q;
   const size_t rows_per_split = (size_t)a.n_q * (QT * 16);
   const __amdgpu_buffer_rsrc_t ro =
-      __builtin_amdgcn_make_buffer_rsrc(a.o_part, 0, (int)(rows_per_split * ns * 128 * sizeof(float)), 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(o_part, 0, (int)(rows_per_split * ns * 128 * sizeof(float)), 0x00020000);
   const __amdgpu_buffer_rsrc_t rm =
-      __builtin_amdgcn_make_buffer_rsrc(a.ml_part, 0, (int)(rows_per_split * ns * 2 * sizeof(float)), 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(ml_part, 0, (int)(rows_per_split * ns * 2 * sizeof(float)), 0x00020000);
   if (has_item) {
     const int off = (int)((((size_t)split * rows_per_split + item_row) * 128 + dg * 8) * sizeof(float));
     const f32x4 s0 = {acc[0], acc[1], acc[2], acc[3]}, s1 = {acc[4], acc[5], acc[6], acc[7]};
@@ -535,9 +554,9 @@ __global__ __launch_bounds__(512) void k_attn_head(HeadAttnArgs a) {
   __syncthreads();
   HSTAMP(5);
   if (tid == 0) {
-    const int ticket = __hip_atomic_fetch_add(&a.tickets[head], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int ticket = __hip_atomic_fetch_add(&tickets[head], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = ticket == ns - 1;
-    if (last) __hip_atomic_store(&a.tickets[head], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
+    if (last) __hip_atomic_store(&tickets[head], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
     s_last = last;
   }
   __syncthreads();
@@ -598,15 +617,18 @@ extern "C" int dfl_debug_read_head_stamps(unsigned long long *host_out) {
 #endif
 
 extern "C" int64_t dfl_attn_head_ws_bytes(int n_q, int max_splits, int q_tiles) {
-  return (int64_t)max_splits * n_q * q_tiles * 16 * (128 + 2) * sizeof(float) + (int64_t)n_q * sizeof(int) + 64;
+  const int64_t b = (int64_t)max_splits * n_q * q_tiles * 16 * (128 + 2) * sizeof(float) + (int64_t)n_q * sizeof(int) + 64;
+  return (b + 15) / 16 * 16;   // per-candidate blocks of a multi-candidate launch stay 16-byte aligned
 }
 
-extern "C" int dfl_attn_head(const void *xq, int64_t ldq, int q_col, int k_col, int v_col, const void *xc, int64_t ldc,
-                             int ck_col, int cv_col, int n_q, int n_kv, const void *q_norm_w, const void *k_norm_w,
-                             float eps, const void *cos_tab, const void *sin_tab, int max_pos, void *kcache,
-                             void *vcache, int cache_rows, float scale, int causal, const int32_t *dyn, int S, int tau,
-                             int bs, int pos0, int q_tiles, void *ws, int max_splits, void *out_frag,
-                             int64_t out_tile_stride, void *stream) {
+namespace {
+int attn_head_launch(const void *xq, int64_t ldq, int q_col, int k_col, int v_col, const void *xc, int64_t ldc, int ck_col,
+                     int cv_col, int n_q, int n_kv, const void *q_norm_w, const void *k_norm_w, float eps,
+                     const void *cos_tab, const void *sin_tab, int max_pos, void *kcache, void *vcache, int cache_rows,
+                     float scale, int causal, const int32_t *dyn, int S, int tau, int bs, int pos0, int q_tiles, void *ws,
+                     int max_splits, void *out_frag, int64_t out_tile_stride, int n_cand, int64_t xq_cand_stride,
+                     int64_t out_cand_stride, void *k_out, void *v_out, int64_t kv_out_cand_stride, int out_rows,
+                     void *stream) {
   DFL_REQUIRE(xq && cos_tab && sin_tab && kcache && vcache && out_frag && ws, "dfl_attn_head: null pointer");
   DFL_REQUIRE((q_norm_w == nullptr) == (k_norm_w == nullptr), "dfl_attn_head: give both norm weights or neither");
   DFL_REQUIRE(n_q > 0 && n_kv > 0 && n_q % n_kv == 0, "dfl_attn_head: bad head counts (n_q=%d n_kv=%d)", n_q, n_kv);
@@ -618,8 +640,14 @@ extern "C" int dfl_attn_head(const void *xq, int64_t ldq, int q_col, int k_col, 
               "dfl_attn_head: lengths S=%d tau=%d bs=%d outside the kernel's range (q_tiles=%d)", S, tau, bs, q_tiles);
   DFL_REQUIRE(tau == 0 || (xc && ldc > 0 && ldc % 8 == 0 && ck_col >= 0 && cv_col >= 0 && ck_col % 8 == 0 && cv_col % 8 == 0),
               "dfl_attn_head: context rows without a context source");
-  DFL_REQUIRE(S + tau + bs <= cache_rows, "dfl_attn_head: S + tau + bs = %d exceeds cache_rows = %d", S + tau + bs, cache_rows);
+  DFL_REQUIRE(S + (k_out ? 0 : tau + bs) <= cache_rows, "dfl_attn_head: S + tau + bs = %d exceeds cache_rows = %d", S + tau + bs,
+              cache_rows);
   DFL_REQUIRE(max_splits >= 1 && out_tile_stride >= 0 && out_tile_stride % 8 == 0, "dfl_attn_head: bad max_splits / out_tile_stride");
+  DFL_REQUIRE(n_cand >= 1 && n_cand <= 64, "dfl_attn_head: n_cand outside 1..64");
+  DFL_REQUIRE(n_cand == 1 || (xq_cand_stride % 8 == 0 && out_cand_stride % 8 == 0 && k_out && v_out),
+              "dfl_attn_head: candidates need 8-element strides and a K/V staging area (they must not write the cache)");
+  DFL_REQUIRE(!k_out == !v_out && (!k_out || (out_rows >= tau + bs && kv_out_cand_stride >= (int64_t)n_kv * out_rows * 128)),
+              "dfl_attn_head: bad K/V staging area");
   // Old-key splits: a workgroup's 8 waves take one 32-key tile each per round, so up to 8 tiles
   // per split cost one round; beyond ~224 workgroups per launch the splits grow instead
   // (S here is the bound the caller sized the launch for when the lengths come from dyn).
@@ -631,7 +659,7 @@ extern "C" int dfl_attn_head(const void *xq, int64_t ldq, int q_col, int k_col, 
   static const int knob_wgs = [] { const char *e = getenv("DFL_ATTN_HEAD_WGS"); return e ? atoi(e) : 224; }();
   const int tiles = knob_tiles < 1 ? 1 : knob_tiles;
   int ns_old = (nt + tiles - 1) / tiles;
-  int budget = knob_wgs / n_q - 1;
+  int budget = knob_wgs / (n_q * n_cand) - 1;
   budget = budget < 1 ? 1 : budget;
   ns_old = ns_old > budget ? budget : ns_old;
   ns_old = ns_old > max_splits - 1 ? max_splits - 1 : ns_old;
@@ -672,7 +700,14 @@ extern "C" int dfl_attn_head(const void *xq, int64_t ldq, int q_col, int k_col, 
   a.ml_part = (float *)ws + rows * 128;
   a.tickets = (int *)((float *)ws + rows * 130);
   a.ns_old = ns_old;
-  const dim3 grid(n_kv, G * (ns_old + 1));
+  a.xq_cand_stride = xq_cand_stride;
+  a.out_cand_stride = out_cand_stride / 8;
+  a.ws_cand_stride = dfl_attn_head_ws_bytes(n_q, max_splits, q_tiles) / 4;
+  a.k_out = (bf16_t *)k_out;
+  a.v_out = (bf16_t *)v_out;
+  a.kv_out_cand_stride = kv_out_cand_stride;
+  a.out_rows = out_rows;
+  const dim3 grid(n_kv, G * (ns_old + 1), n_cand);
   hipStream_t st = (hipStream_t)stream;
   if (q_tiles == 1)
     hipLaunchKernelGGL(k_attn_head<1>, grid, dim3(512), 0, st, a);
@@ -680,4 +715,29 @@ extern "C" int dfl_attn_head(const void *xq, int64_t ldq, int q_col, int k_col, 
     hipLaunchKernelGGL(k_attn_head<2>, grid, dim3(512), 0, st, a);
   DFL_CHECK_LAUNCH("dfl_attn_head");
   return DFL_OK;
+}
+}  // namespace
+
+extern "C" int dfl_attn_head(const void *xq, int64_t ldq, int q_col, int k_col, int v_col, const void *xc, int64_t ldc,
+                             int ck_col, int cv_col, int n_q, int n_kv, const void *q_norm_w, const void *k_norm_w,
+                             float eps, const void *cos_tab, const void *sin_tab, int max_pos, void *kcache,
+                             void *vcache, int cache_rows, float scale, int causal, const int32_t *dyn, int S, int tau,
+                             int bs, int pos0, int q_tiles, void *ws, int max_splits, void *out_frag,
+                             int64_t out_tile_stride, void *stream) {
+  return attn_head_launch(xq, ldq, q_col, k_col, v_col, xc, ldc, ck_col, cv_col, n_q, n_kv, q_norm_w, k_norm_w, eps, cos_tab,
+                          sin_tab, max_pos, kcache, vcache, cache_rows, scale, causal, dyn, S, tau, bs, pos0, q_tiles, ws,
+                          max_splits, out_frag, out_tile_stride, 1, 0, 0, nullptr, nullptr, 0, 0, stream);
+}
+
+extern "C" int dfl_attn_head_cand(const void *xq, int64_t ldq, int q_col, int k_col, int v_col, int n_cand,
+                                  int64_t xq_cand_stride, int n_q, int n_kv, const void *q_norm_w, const void *k_norm_w,
+                                  float eps, const void *cos_tab, const void *sin_tab, int max_pos, const void *kcache,
+                                  const void *vcache, int cache_rows, float scale, int S, int bs, void *ws, int max_splits,
+                                  void *out_frag, int64_t out_cand_stride, void *k_out, void *v_out,
+                                  int64_t kv_out_cand_stride, int out_rows, void *stream) {
+  DFL_REQUIRE(n_cand >= 1 && k_out && v_out, "dfl_attn_head_cand: needs the K/V staging area");
+  return attn_head_launch(xq, ldq, q_col, k_col, v_col, nullptr, 0, 0, 0, n_q, n_kv, q_norm_w, k_norm_w, eps, cos_tab, sin_tab,
+                          max_pos, const_cast<void *>(kcache), const_cast<void *>(vcache), cache_rows, scale, 1, nullptr, S, 0,
+                          bs, S, 1, ws, max_splits, out_frag, 0, n_cand, xq_cand_stride, out_cand_stride, k_out, v_out,
+                          kv_out_cand_stride, out_rows, stream);
 }

@@ -116,6 +116,7 @@ class DecodeSession:
         self.hook_calls = 0
         self.stopped = False
         self.events = None  # set to a dict to have cycle() record (start, end) event pairs per phase
+        self.draft_logits = None  # set to a bf16 [32, V] buffer to have the draft's logits materialised into it
         # the tapped rows live here from a verify to the next draft (own buffer: several
         # sessions may be interleaved on one NativeTarget)
         self.taps_buf = (torch.zeros(32, len(model.target_layer_ids) * model.config.hidden_size, dtype=torch.bfloat16,
@@ -153,7 +154,7 @@ class DecodeSession:
             hid = m.draft_block(self.dcache, th_rows=ctx, tau=ctx.shape[0], bs=bs, pos0=S, block_ids=blk[0],
                                 embed=self.embed_w)
             self._mark("lm_head", 0)
-            _draft_ids(m, hid, self.lm_wp, bs, blk, self.draft_temperature)
+            _draft_ids(m, hid, self.lm_wp, bs, blk, self.draft_temperature, self.draft_logits)
             self._mark("lm_head", 1)
             if self.hook is not None:
                 self.hook(blk, self.start, self.hook_calls)
@@ -308,16 +309,19 @@ def run_decode(model, target, input_ids: torch.Tensor, *, mask_token_id: int, ma
                            cycle_trace=cycle_trace, profile_summary=profile_summary)
 
 
-def _draft_ids(model, hid_frag, lm_wp, bs, blk, draft_temperature):
+def _draft_ids(model, hid_frag, lm_wp, bs, blk, draft_temperature, keep_logits=None):
     """blk[0, 1:bs] <- draft tokens.  Greedy (every loop but the policy one at T>0):
     fused lm_head GEMM + argmax.  benchmark_dynamic_schedule.py:342 samples the draft
     with the temperature: then the logits are materialised by the same GEMM and the
-    reference's softmax + multinomial is applied to them."""
+    reference's softmax + multinomial is applied to them.  keep_logits (bf16 [16 * tiles, V]): the caller's
+    buffer for the materialised logits (the multi-candidate loop builds its candidates from them)."""
     if draft_temperature < 1e-5:
-        model.draft_tokens(hid_frag, lm_wp, bs, blk[0])
+        model.draft_tokens(hid_frag, lm_wp, bs, blk[0], logits=keep_logits)
         return
     V = model.config.vocab_size
-    logits = torch.empty(16 * ((bs + 15) // 16), V, dtype=torch.bfloat16, device=model.device)
+    logits = keep_logits
+    if logits is None:
+        logits = torch.empty(16 * ((bs + 15) // 16), V, dtype=torch.bfloat16, device=model.device)
     model.draft_tokens(hid_frag, lm_wp, bs, blk[0], logits=logits)
     blk[:, 1:bs] = sample(logits[1:bs].unsqueeze(0), draft_temperature)
 

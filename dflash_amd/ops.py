@@ -279,6 +279,51 @@ def attn_head(*, xq: torch.Tensor, q_col: int, k_col: int, v_col: int, n_q: int,
         _p(out_frag, BF16, "out_frag"), out_tile_stride, _stream()), "dfl_attn_head")
 
 
+def attn_head_cand(*, xq: torch.Tensor, q_col: int, k_col: int, v_col: int, n_q: int, n_kv: int, q_norm_w, k_norm_w, eps,
+                   cos_tab, sin_tab, kcache, vcache, scale: float, S: int, bs: int, ws, max_splits: int,
+                   out_frag: torch.Tensor, k_out: torch.Tensor, v_out: torch.Tensor) -> None:
+    """xq [C, 16, ldq] bf16 candidate block rows; out_frag [C, 16*n_q*128]; k_out / v_out [C, n_kv, rows, 128]:
+    the candidates' new K/V rows (rows 0..bs-1), NOT written to the cache."""
+    assert xq.is_cuda and xq.dtype == BF16 and xq.dim() == 3 and xq.stride(2) == 1 and xq.shape[1] >= 16
+    assert out_frag.dim() == 2 and out_frag.is_contiguous() and out_frag.shape[0] >= xq.shape[0]
+    assert k_out.shape == v_out.shape and k_out.dim() == 4 and k_out.shape[3] == 128 and k_out.is_contiguous()
+    assert v_out.is_contiguous() and k_out.shape[0] >= xq.shape[0] and k_out.shape[1] == n_kv
+    assert kcache.shape == vcache.shape and kcache.dim() == 3 and kcache.shape[2] == 128
+    check(lib().dfl_attn_head_cand(
+        xq.data_ptr(), xq.stride(1), q_col, k_col, v_col, xq.shape[0], xq.stride(0), n_q, n_kv,
+        _p(q_norm_w, BF16, "q_norm_w"), _p(k_norm_w, BF16, "k_norm_w"), eps, _p(cos_tab, BF16, "cos"),
+        _p(sin_tab, BF16, "sin"), cos_tab.shape[0], _p(kcache, BF16, "kcache"), _p(vcache, BF16, "vcache"),
+        kcache.shape[1], scale, S, bs, _p(ws), max_splits, _p(out_frag, BF16, "out_frag"), out_frag.stride(0),
+        _p(k_out, BF16, "k_out"), _p(v_out, BF16, "v_out"), k_out.stride(0), k_out.shape[2], _stream()),
+        "dfl_attn_head_cand")
+
+
+def topk_rows(logits: torch.Tensor, k: int):
+    """logits bf16 [rows, V] (unit inner stride) -> (values fp32 [rows, 8], indices int32 [rows, 8], lse fp32 [rows]);
+    columns >= k are unspecified.  Order: value descending, index ascending."""
+    assert logits.is_cuda and logits.dtype == BF16 and logits.dim() == 2 and logits.stride(1) == 1
+    rows, V = logits.shape
+    val = torch.empty(rows, 8, dtype=F32, device=logits.device)
+    idx = torch.empty(rows, 8, dtype=I32, device=logits.device)
+    lse = torch.empty(rows, dtype=F32, device=logits.device)
+    check(lib().dfl_topk_rows(logits.data_ptr(), logits.stride(0), rows, V, k, _p(val), _p(idx), _p(lse), _stream()),
+          "dfl_topk_rows")
+    return val, idx, lse
+
+
+def candidate_select(blocks: torch.Tensor, posterior: torch.Tensor, scores: torch.Tensor, bs: int, output_ids, dyn,
+                     stop_ids, result: torch.Tensor) -> None:
+    """blocks / posterior int64 [C, >= bs]; scores fp32 [C]; result int32 [12]."""
+    assert blocks.dim() == 2 and posterior.dim() == 2 and blocks.stride(1) == 1 and posterior.stride(1) == 1
+    assert result.numel() >= 12 and scores.numel() >= blocks.shape[0]
+    n_stop = 0 if stop_ids is None else stop_ids.numel()
+    check(lib().dfl_candidate_select(
+        _p(blocks[0], I64, "blocks"), blocks.stride(0), _p(posterior[0], I64, "posterior"), posterior.stride(0),
+        _p(scores, F32, "scores"), blocks.shape[0], bs, _p(output_ids, I64, "output_ids"), output_ids.numel(),
+        _p(dyn, I32, "dyn"), _p(stop_ids, I64, "stop_ids") if n_stop else None, n_stop, _p(result, I32, "result"),
+        _stream()), "dfl_candidate_select")
+
+
 def argmax(logits: torch.Tensor) -> torch.Tensor:
     """First-max-index argmax over the last axis, int64 (model/utils.py:28-29)."""
     if logits.dtype not in (BF16, F32):

@@ -227,6 +227,39 @@ int dfl_attn_head(const void *xq, int64_t ldq, int q_col, int k_col, int v_col, 
                   float scale, int causal, const int32_t *dyn, int S, int tau, int bs, int pos0, int q_tiles,
                   void *ws, int max_splits, void *out_frag, int64_t out_tile_stride, void *stream);
 
+/* ---- multi-candidate verify (benchmark_candidate_solutions.py) ----
+ * Several drafts of ONE block are verified against ONE cached prefix and the best is kept (:570-618).
+ *
+ * dfl_attn_head_cand: dfl_attn_head (causal, no context rows, q_tiles = 1) for n_cand candidate blocks in one launch
+ * (grid.z = candidate): candidate c's block rows at xq + c * xq_cand_stride elements, its frag16 output at out_frag +
+ * c * out_cand_stride elements; every candidate attends the same cached rows [0, S) plus ITS OWN bs new rows, which go
+ * not to the cache but to the staging area k_out / v_out [c][n_kv][out_rows][128] (rows 0..bs-1) — the reference clones
+ * and batch-repeats the whole DynamicCache instead (:76-81, :572-575) and selects the winner's copy (:604-608); here the
+ * caller copies the winner's bs rows into the cache.  ws: n_cand * dfl_attn_head_ws_bytes(n_q, max_splits, 1), zeroed. */
+int dfl_attn_head_cand(const void *xq, int64_t ldq, int q_col, int k_col, int v_col, int n_cand, int64_t xq_cand_stride,
+                       int n_q, int n_kv, const void *q_norm_w, const void *k_norm_w, float eps, const void *cos_tab,
+                       const void *sin_tab, int max_pos, const void *kcache, const void *vcache, int cache_rows,
+                       float scale, int S, int bs, void *ws, int max_splits, void *out_frag, int64_t out_cand_stride,
+                       void *k_out, void *v_out, int64_t kv_out_cand_stride, int out_rows, void *stream);
+
+/* Per row of bf16 logits [rows][ld] (rows <= 64): the k <= 8 largest values with their indices, ordered (value
+ * descending, index ascending) — out_val fp32 [rows][8], out_idx int32 [rows][8] — and the row's log-sum-exp (fp32).
+ * What the candidate builders take from the 15 x V draft logits: torch.topk at :216, :296, the top-2 probability
+ * margin softmax(x)[top1] - softmax(x)[top2] = exp(v1 - lse) - exp(v2 - lse) at :98-101, :305-307, and
+ * log_softmax(x)[token] = x[token] - lse at :119-131.  torch.topk's order among EQUAL values is an implementation
+ * detail; this one is fixed (and equals torch.argmax's for k = 1). */
+int dfl_topk_rows(const void *logits, int64_t ld, int rows, int V, int k, float *out_val, int32_t *out_idx, float *out_lse,
+                  void *stream);
+
+/* Acceptance length of every candidate block against its posterior, the choice of :592-601 — maximise tau, then the
+ * draft score, then prefer the lower candidate index, evaluated as the reference does: argmax over the fp32 value
+ * tau * 1e6 + draft_score - idx * 1e-3 — and the winner's commit (:612-613) with the stop test and length bookkeeping
+ * of dfl_accept_commit.  blocks / posterior int64 [n_cand][stride], scores fp32 [n_cand], n_cand <= 8.
+ * result int32 [12]: {acc, new_start, stop, winner, acc of candidate 0..7 (-1 beyond n_cand)}. */
+int dfl_candidate_select(const int64_t *blocks, int64_t blk_stride, const int64_t *posterior, int64_t post_stride,
+                         const float *scores, int n_cand, int bs, int64_t *output_ids, int64_t output_len, int32_t *dyn,
+                         const int64_t *stop_ids, int n_stop, int32_t *result, void *stream);
+
 /* First-max-index argmax over the last axis (model/utils.py:28-29).
  * dtype: 0 = bf16, 1 = fp32.  ids int64 [rows]. */
 int dfl_argmax(const void *logits, int dtype, int rows, int64_t V, int64_t *ids, void *stream);

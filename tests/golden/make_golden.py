@@ -17,6 +17,7 @@ Fixtures (SURVEY.md §8c list):
   G5 scheduler.json            EWMAPerformanceScheduler decision traces
   G6 sample_t.npz              sample(logits, 0.7) under torch.manual_seed
   G7 harness.json              summarize_mode / summarize_profile of benchmark.py
+  G9 candidates.json           candidate builders + budget rule of benchmark_candidate_solutions.py
   G8 draft_forward_*_wide.npz, e2e_wide.json   block sizes 17..32 (forward vectors; loop runs at 20 / 24 / 32, policy)
 """
 import json
@@ -367,7 +368,74 @@ def gen_wide():
     print("G8 done")
 
 
+# ---------------------------------------------------------------- G9: multi-candidate verify (SURVEY.md §8f-4)
+def _distinct_bf16_logits(g, rows, V, spread):
+    """[1, rows, V] bf16 logits whose values are pairwise distinct inside a row, so that torch.topk / argsort have
+    ONE answer (bf16 lm_head outputs tie often, and topk's order among ties is an implementation detail)."""
+    bits = torch.arange(0x3C00, 0x4180, dtype=torch.int32)               # bf16 patterns of 0.0078 .. 16: all distinct
+    pool = torch.cat([bits, bits | 0x8000]).to(torch.int16).view(torch.bfloat16)
+    pool = pool[pool.float().abs() <= spread]
+    assert pool.numel() >= V, (pool.numel(), V)
+    out = torch.empty(1, rows, V, dtype=torch.bfloat16)
+    for r in range(rows):
+        out[0, r] = pool[torch.randperm(pool.numel(), generator=g)[:V]]
+    return out
+
+
+def gen_candidates():
+    """Candidate builders of benchmark_candidate_solutions.py (:84-414) — pure functions of (block ids, draft logits,
+    parameters) — run as imported; the loop around them (:570-618) cannot run on transformers 5.15
+    (DynamicCache.to_legacy_cache is gone), so what is stored is every builder's output plus the budget rule."""
+    import benchmark_candidate_solutions as ref_cand  # noqa: E402  (reference)
+    g = torch.Generator().manual_seed(77)
+    V = 2048
+    cases = []
+
+    def meta_list(meta):
+        return [{k: (v if not isinstance(v, float) else float(v)) for k, v in m.items()} for m in meta]
+
+    for ci, (bs, spread) in enumerate(((16, 8.0), (16, 2.0), (12, 8.0), (5, 4.0), (2, 8.0), (16, 16.0))):
+        logits = _distinct_bf16_logits(g, bs - 1, V, spread)
+        block = torch.randint(0, V, (1, bs), generator=g)
+        block[:, 1:] = ref_sample(logits)                       # the loop's greedy fill (:529)
+        case = {"bs": bs, "block": block[0].tolist(),
+                "logits_bits": logits.view(torch.int16)[0].numpy().astype(np.int16).tolist(), "runs": []}
+        for depth, thr, topk, maxc in ((6, -1.0, 2, 4), (3, -1.0, 3, 8), (6, 0.3, 2, 4), (6, 0.02, 2, 4), (1, -1.0, 2, 1)):
+            pos = ref_cand.select_branch_positions(logits, bs, depth, thr)
+            cands, meta = ref_cand.build_candidate_blocks(block, logits, pos, topk, maxc)
+            case["runs"].append({"mode": "branch_beam", "branch_depth": depth, "margin_threshold": thr,
+                                 "branch_top_k": topk, "max_candidates": maxc, "selected_positions": pos,
+                                 "candidates": [c[0].tolist() for c in cands], "meta": meta_list(meta)})
+        for fpl, topk, maxc in ((5, 4, 4), (2, 2, 8), (20, 4, 4), (5, 1, 4), (1, 8, 8), (5, 4, 3)):
+            cands, meta, pos = ref_cand.build_fixed_prefix_rank_candidates(block, logits, fpl, topk, maxc)
+            case["runs"].append({"mode": "fixed_prefix_rank", "fixed_prefix_len": fpl, "branch_top_k": topk,
+                                 "max_candidates": maxc, "selected_positions": pos,
+                                 "candidates": [c[0].tolist() for c in cands], "meta": meta_list(meta)})
+        for fpl, topk, maxc, smp, thr in ((5, 4, 4, 4, -1.0), (2, 3, 8, 2, -1.0), (5, 4, 4, 4, 0.3), (5, 4, 4, 4, 1e-9),
+                                          (1, 2, 6, 8, -1.0), (5, 1, 4, 4, -1.0)):
+            cands, meta, pos = ref_cand.build_uncertainty_sparse_rank_candidates(block, logits, fpl, topk, maxc, smp, thr)
+            case["runs"].append({"mode": "uncertainty_sparse_rank", "fixed_prefix_len": fpl, "branch_top_k": topk,
+                                 "max_candidates": maxc, "sparse_max_positions": smp, "margin_threshold": thr,
+                                 "selected_positions": pos, "candidates": [c[0].tolist() for c in cands],
+                                 "meta": meta_list(meta)})
+        cases.append(case)
+    budget = []
+    for enabled in (False, True):
+        for cyc in (0, 1, 2, 3, 5, 8, 10):
+            for ratio in (None, 0.9, 0.85, 0.7, 0.65, 0.3):
+                for maxc in (8, 2):
+                    kw = dict(enabled=enabled, max_candidates=maxc, cycle_idx=cyc, last_accept_ratio=ratio,
+                              budgets=(1, 4, 8), accept_thresholds=(0.85, 0.65), warmup_cycles=2, probe_interval=5)
+                    budget.append({**{k: (list(v) if isinstance(v, tuple) else v) for k, v in kw.items()},
+                                   "out": ref_cand.resolve_cycle_max_candidates(**kw)})
+    json.dump({"vocab": V, "cases": cases, "budget": budget}, open(os.path.join(HERE, "candidates.json"), "w"))
+    print("G9 done", sum(len(c["runs"]) for c in cases), "builder runs")
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["candidates"]:
+        gen_candidates()
+        sys.exit(0)
     if sys.argv[1:] == ["wide"]:     # later additions are generated alone: the round-1 fixtures stay byte-identical
         gen_wide()
         sys.exit(0)
@@ -385,3 +453,4 @@ if __name__ == "__main__":
     gen_sample_t()
     gen_harness()
     gen_wide()
+    gen_candidates()
