@@ -140,10 +140,20 @@ def gpu_leg(args, rank, world, dev):
             wrong = G[start + k + 1]
             blk[0, k + 1] = torch.where(blk[0, k + 1] == wrong, (wrong + 1) % 151000, blk[0, k + 1])
 
-    s = DecodeSession(draft, target, prompt, mask_token_id=mask_id, max_new_tokens=need, max_block_size=bs,
-                      stop_token_ids=None, temperature=0.0, draft_token_hook=hook)
-    s.prefill()
-    s.cycle(bs)                      # cycle 0: carries the one-off 1024-row draft-context prefill
+    for rep in range(2):   # rep 0 pays the one-off costs (code-object loads, allocator, HF lazy init): rep 1 is reported
+        s = DecodeSession(draft, target, prompt, mask_token_id=mask_id, max_new_tokens=need, max_block_size=bs,
+                          stop_token_ids=None, temperature=0.0, draft_token_hook=hook)
+        torch.cuda.synchronize()
+        t_pf = time.perf_counter()
+        s.prefill()
+        torch.cuda.synchronize()
+        t_c0 = time.perf_counter()
+        s.cycle(bs)                  # cycle 0: carries the one-off 1024-row draft-context prefill
+        torch.cuda.synchronize()
+        ttft_side = {"target_prefill_ms": 1e3 * (t_c0 - t_pf), "cycle0_ms": 1e3 * (time.perf_counter() - t_c0),
+                     "note": "second request on warm code (outside the timed region): the target prefill runs through the "
+                             f"wrapped HF model; cycle 0 = projection of the {P} prompt context rows into the draft cache "
+                             "(model/dflash.py:73-85, 64 rows per pass) + one decode cycle"}
     s.cycle(bs)                      # first steady-state cycle: one-off code-object loads (60 ms) — setup, like cycle 0
     for _ in range(args.warmup):
         s.cycle(bs)
@@ -176,10 +186,22 @@ def gpu_leg(args, rank, world, dev):
     from dflash_amd import distributed as D
     dt_max, tok_sum = D.reduce_timing(dt, float(tokens), device=dev)
     _, cyc_sum = D.reduce_timing(dt, float(args.steps), device=dev)
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r1_pmc_lm_head.json")
-    if os.path.exists(pmc):  # PMC passes cannot run inside the timed bench: committed summary of the same kernel
-        traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+    # PMC passes cannot run inside the timed bench (rocprofv3 --pmc serialises and slows the run): `traffic` is the
+    # committed per-launch HBM byte count of this very kernel — accepted only while the hash of the kernel's sources
+    # stored beside it still matches (scripts/pmc_lm_head_json.py); a changed kernel reports null until re-profiled
+    traffic, traffic_note = None, "no PMC summary for the current kernel sources"
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    try:
+        from pmc_lm_head_json import source_hash
+        for fn in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+            if fn.endswith("_pmc_lm_head.json"):
+                rec = json.load(open(os.path.join(ROOT, "profiles", fn)))
+                if rec.get("kernel_source_sha256_16") == source_hash():
+                    traffic = rec.get("hbm_bytes_per_launch")
+                    traffic_note = f"profiles/{fn} (kernel sources unchanged since)"
+                    break
+    except Exception as e:   # never let bookkeeping break the measurement
+        traffic_note = f"PMC summary not read: {type(e).__name__}"
     kv_bytes = 20480 * (P + 16)
     hot_bytes = DRAFT_WEIGHT_BYTES + LM_HEAD_BYTES + kv_bytes
     return dict(
@@ -190,12 +212,13 @@ def gpu_leg(args, rank, world, dev):
                   "frac": LM_HEAD_BYTES / (lm_ms * 1e-3) / 1e9 / 8000.0, "traffic": traffic,
                   "bytes_per_launch": LM_HEAD_BYTES, "avg_ms": lm_ms,
                   "note": "achieved/avg_ms from stream events around the launch in the timed region (the pair also "
-                          "spans the 16-wave argmax finish kernel); traffic = 2*FETCH_SIZE+WRITE_SIZE bytes from "
-                          "profiles/r1_pmc_summary.csv"},
+                          "spans the 16-wave argmax finish kernel); traffic = 2*FETCH_SIZE+WRITE_SIZE bytes per launch: "
+                          + traffic_note},
         hot_path={"draft_plus_lm_head_ms_per_cycle": draft_ms, "target_verify_ms_per_cycle": target_ms,
                   "algorithmic_bytes_per_cycle": hot_bytes,
                   "achieved_GBps": hot_bytes / (draft_ms * 1e-3) / 1e9,
                   "frac_of_8TBps": hot_bytes / (draft_ms * 1e-3) / 1e9 / 8000.0},
+        ttft_side=ttft_side,
     )
 
 
@@ -472,7 +495,7 @@ def main():
                        "target_verify": "hf" if args.hf_verify else "native", "parallelism": f"dp{world}"},
             "mean_acceptance_length": res["mean_tau"], "raw_tau1_value": res["raw_tau1_value"],
             "lossless_fraction": res["lossless_fraction"], "roofline": res["roofline"], "hot_path": res["hot_path"],
-            "cpu_baseline": cpu,
+            "ttft_side": res.get("ttft_side"), "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if use_pg:

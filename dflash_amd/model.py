@@ -80,6 +80,7 @@ class DFlashDraftModel:
         self._rope = None
         # "head": dfl_attn_head on finished bf16 q/k/v rows (round 2); "fused": round-1 stage on fp32 partials
         self.attn_impl = "head"
+        self.wide_prefill = True   # False: the round-1 context prefill in 16-row groups (kept for A/B timing and tests)
 
     # ------------------------------------------------------------------ weights
     def eval(self):
@@ -120,6 +121,7 @@ class DFlashDraftModel:
         # each layer's packed qkv, concatenated): the context rows' K/V of every layer depend only on the
         # context rows, so one GEMM per cycle produces them all (model/dflash.py:73-78, context half)
         w["kv_all"] = torch.cat([lw["qkv"][c.q_dim * c.hidden_size:] for lw in w["layers"]]).contiguous()
+        w["k_norm_all"] = torch.stack([lw["k_norm"] for lw in w["layers"]]).contiguous()
         torch.cuda.synchronize(self.device)
         self.w = w
         self._ws = None  # row sources point at the weights: rebuild with them
@@ -222,11 +224,52 @@ class DFlashDraftModel:
                       part=ws["part"], nsplit=self.ks_fc, part_split=16 * c.hidden_size, ldp=c.hidden_size,
                       dyn=dyn if dyn_word is not None else None, dyn_word=dyn_word or 0)
 
+    def _prefill_ws(self):
+        if getattr(self, "_pws", None) is None:
+            c, d, MT = self.config, self.device, 4
+            H, nkv = c.hidden_size, c.num_hidden_layers * 2 * c.kv_dim
+            z = lambda *s_, dt=BF16: torch.zeros(*s_, dtype=dt, device=d)  # noqa: E731
+            self._pws = dict(taps=z(MT, 16, c.fc_in), ctxh=z(MT, 16, H), xn=z(MT, 16 * H),
+                             part=z(ops.batch_ksplit(H) * MT * 16 * nkv, dt=torch.float32),
+                             dyn=z(MT, 8, dt=torch.int32),
+                             gws=torch.zeros(ops.lib().dfl_gemm_batch_ws_bytes(H, c.fc_in), dtype=torch.uint8, device=d))
+            p = self._pws
+            p["src_taps"], p["src_xn"] = ops.brows_plain(p["taps"], ops.DYN_TAU), ops.brows_frag(p["xn"])
+        return self._pws
+
+    def _prefill_context_wide(self, cache: DFlashKVCache, th: torch.Tensor, pos0: int) -> None:
+        """The prompt's context rows 64 at a time (four 16-row tiles of the ragged-batch GEMMs, model/dflash.py:73-85
+        for ctx = P rows): per pass ONE stream of fc (168 MB) and of the 5 layers' k/v weights (84 MB) and five launches
+        (fc, hidden_norm, k/v GEMM of all layers, K/V append of all layers) — instead of re-streaming both per 16-row
+        group with 12 launches each (P = 1024: 4 GB and 80 launches instead of 13 GB and ~700)."""
+        c, w, p = self.config, self.w, self._prefill_ws()
+        MT, H, L = 4, c.hidden_size, c.num_hidden_layers
+        nkv = L * 2 * c.kv_dim
+        n, S = th.shape[0], cache.length
+        cos, sin = self._rope_tab(pos0 + n + 64)
+        nsp = ops.batch_ksplit(H)
+        for g0 in range(0, n, 64):
+            rows = min(64, n - g0)
+            R = (rows + 15) // 16
+            rec = [[S + g0 + 16 * r, max(0, min(16, rows - 16 * r)), 0, pos0 + g0 + 16 * r, 0, 0, 0, 0] for r in range(MT)]
+            p["dyn"].copy_(torch.tensor(rec, dtype=torch.int32))
+            p["taps"].view(MT * 16, c.fc_in)[:rows].copy_(th[g0:g0 + rows])
+            ops.gemm_resid_batch(w["fc"], p["src_taps"], R, H, c.fc_in, p["ctxh"], add_residual=False, ws=p["gws"],
+                                 dyn=p["dyn"])
+            ops.norm_frag_batch(p["ctxh"], R, w["hidden_norm"], c.rms_norm_eps, p["xn"], p["dyn"], ops.DYN_TAU)
+            ops.gemm_f32_batch(w["kv_all"], p["src_xn"], R, nkv, H, p["part"], p["dyn"])
+            ops.kv_append_batch(kv=p["part"], nsplit=nsp, split_stride=ops.batch_tiles(R) * 16 * nkv, ld=nkv, k_col=0,
+                                v_col=c.kv_dim, col_layer_stride=2 * c.kv_dim, n_layers=L, R=R,
+                                n_kv=c.num_key_value_heads, k_norm_w=w["k_norm_all"], eps=c.rms_norm_eps, cos_tab=cos,
+                                sin_tab=sin, kcache=cache.k, vcache=cache.v, dyn=p["dyn"])
+        cache.length = S + n
+
     def prefill_context(self, cache: DFlashKVCache, target_hidden: torch.Tensor, pos0: int) -> None:
         """Append K/V of `target_hidden` rows (context only, no block) to the cache at
-        rows/positions cache.length.., in 16-row groups.  Cycle 0 of the reference
-        projects the P prompt rows together with the first block (model/dflash.py:73-85);
-        K/V rows are row-independent, so doing them first is the same arithmetic."""
+        rows/positions cache.length...  Cycle 0 of the reference projects the P prompt rows
+        together with the first block (model/dflash.py:73-85); K/V rows are row-independent, so
+        doing them first is the same arithmetic.  More than 16 rows go 64 at a time through the
+        ragged-batch GEMMs (`_prefill_context_wide`), up to 16 through the single-tile kernels."""
         c, ws, w = self.config, self._workspace(), self.w
         th = target_hidden.reshape(-1, c.fc_in)
         if th.dtype != BF16:
@@ -235,6 +278,8 @@ class DFlashDraftModel:
         S = cache.length
         if S + n > cache.max_rows:
             raise ValueError("draft KV cache too small")
+        if n > 16 and self.wide_prefill:
+            return self._prefill_context_wide(cache, th, pos0)
         cos, sin = self._rope_tab(pos0 + n + 64)
         ops.set_dyn(cache.dyn, S, 0, 0, pos0)
         nkv2 = 2 * c.kv_dim

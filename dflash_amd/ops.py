@@ -474,13 +474,20 @@ def norm_frag_batch(h: torch.Tensor, R: int, norm_w: torch.Tensor, eps: float, f
 
 def kv_append_batch(*, kv, nsplit, split_stride, ld, k_col, v_col, col_layer_stride, n_layers, R, n_kv, k_norm_w,
                     eps, cos_tab, sin_tab, kcache, vcache, dyn) -> None:
-    """kcache/vcache [MT, L, n_kv, rows, 128]; k_norm_w [L, 128] or None."""
-    assert kcache.shape == vcache.shape and kcache.dim() == 5 and kcache.shape[4] == 128 and kcache.is_contiguous()
+    """kcache/vcache [MT, L, n_kv, rows, 128]; k_norm_w [L, 128] or None.  A 4-D cache [L, n_kv, rows, 128] is ONE
+    request's cache shared by all R tiles (request stride 0): the tiles are then consecutive 16-row groups of that
+    request's context rows (the large-M context prefill), each with its own S / pos0 in its dyn record."""
+    assert kcache.shape == vcache.shape and kcache.shape[-1] == 128 and kcache.is_contiguous() and vcache.is_contiguous()
+    if kcache.dim() == 4:
+        rows, req_stride, layer_stride = kcache.shape[2], 0, kcache.stride(0)
+    else:
+        assert kcache.dim() == 5
+        rows, req_stride, layer_stride = kcache.shape[3], kcache.stride(0), kcache.stride(1)
     check(lib().dfl_kv_append_batch(
         _p(kv, F32, "kv"), nsplit, split_stride, ld, k_col, v_col, col_layer_stride, n_layers, R, 16, n_kv,
         _p(k_norm_w, BF16, "k_norm_w"), 128, eps, _p(cos_tab, BF16, "cos"), _p(sin_tab, BF16, "sin"),
-        cos_tab.shape[0], _p(kcache, BF16, "kcache"), _p(vcache, BF16, "vcache"), kcache.shape[3],
-        kcache.stride(0), kcache.stride(1), _p(dyn, I32, "dyn"), _stream()), "dfl_kv_append_batch")
+        cos_tab.shape[0], _p(kcache, BF16, "kcache"), _p(vcache, BF16, "vcache"), rows,
+        req_stride, layer_stride, _p(dyn, I32, "dyn"), _stream()), "dfl_kv_append_batch")
 
 
 def attn_fused_batch_ws(R: int, n_q: int, n_kv: int, max_splits: int, device) -> torch.Tensor:

@@ -630,3 +630,36 @@ def test_native_target_wide_blocks_lossless_walk():
                                 draft_token_hook=hook)
     assert rp.output_ids[0].tolist() == G[:33 + n_new].tolist()
     assert set(rp.used_block_sizes) & {20, 24}
+
+
+@pytest.mark.parametrize("P", [17, 64, 100, 1000])
+def test_wide_context_prefill_equals_group_prefill(P):
+    """The prompt's context rows through the 64-row passes of the ragged-batch GEMMs (model/dflash.py:73-85 at ctx = P)
+    vs the 16-row-group path: the same K/V rows in every layer (V up to the rounding of a different K-split order, K
+    likewise after its RoPE), both within tolerance of the oracle on the CPU."""
+    from oracle import dflash_oracle as O
+    cfg = H.tiny_cfg()
+    m = make_model(cfg)
+    g = torch.Generator().manual_seed(P)
+    th = (torch.randn(1, P, cfg.fc_in, generator=g) * 1.5).to(BF16)
+    ca, cb = m.new_cache(P + 64), m.new_cache(P + 64)
+    m.wide_prefill = True
+    m.prefill_context(ca, th[0].to(dev()), 5)
+    m.wide_prefill = False
+    m.prefill_context(cb, th[0].to(dev()), 5)
+    m.wide_prefill = True
+    assert ca.get_seq_length() == cb.get_seq_length() == P
+    for li in range(cfg.num_hidden_layers):
+        H.assert_close(f"wide prefill K l{li} P{P}", ca.k[li][:, :P], cb.k[li][:, :P], max_rel=2 ** -6, mean_rel=1e-3)
+        H.assert_close(f"wide prefill V l{li} P{P}", ca.v[li][:, :P], cb.v[li][:, :P], max_rel=2 ** -6, mean_rel=1e-3)
+    assert int(torch.count_nonzero(ca.k[:, :, P:])) == 0 and int(torch.count_nonzero(ca.v[:, :, P:])) == 0
+    if P <= 100:   # and against the oracle: K/V of the context rows as the reference caches them (positions 5..)
+        w = H.draft_weights(cfg, dtype=BF16)
+        oc = H.oracle_cfg(cfg, "sdpa")
+        oc_cache = O.ListKVCache()
+        ne = torch.zeros(1, 1, cfg.hidden_size, dtype=BF16)
+        O.draft_forward(w, oc, position_ids=torch.arange(5, 5 + P + 1)[None], noise_embedding=ne, target_hidden=th,
+                        cache=oc_cache)
+        for li in range(cfg.num_hidden_layers):
+            H.assert_close(f"wide prefill vs oracle K l{li}", ca.k[li][:, :P], oc_cache.k[li][0][:, :P], max_rel=H.KV_MAX_REL)
+            H.assert_close(f"wide prefill vs oracle V l{li}", ca.v[li][:, :P], oc_cache.v[li][0][:, :P], max_rel=H.KV_MAX_REL)
