@@ -58,6 +58,8 @@ SIGNATURES = {
                            _p, _i, _i, _i, _i, _i, _p, _i, _p, _i64, _p]),
     "dfl_attn_head_cand": (_i, [_p, _i64, _i, _i, _i, _i, _i64, _i, _i, _p, _p, _f, _p, _p, _i, _p, _p, _i, _f, _i, _i,
                                 _p, _i, _p, _i64, _p, _p, _i64, _i, _p]),
+    "dfl_attn_head_batch": (_i, [_p, _i64, _i, _i, _i, _i, _i64, _i, _i, _p, _p, _f, _p, _p, _i, _p, _p, _i, _i64, _f, _i,
+                                 _p, _i, _p, _i, _p, _i64, _p]),
     "dfl_topk_rows": (_i, [_p, _i64, _i, _i, _i, _p, _p, _p, _p]),
     "dfl_candidate_select": (_i, [_p, _i64, _p, _i64, _p, _i, _i, _p, _i64, _p, _p, _i, _p, _p]),
     "dfl_argmax": (_i, [_p, _i, _i, _i64, _p, _p]),

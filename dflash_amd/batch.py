@@ -98,13 +98,18 @@ class BatchedDecoder:
                       act=z(MT, 16 * t.I), part_qkv=z(ks(H) * MT * 16 * t.nqkv, dt=F32),
                       part_h=z(max(ks(t.q_dim), ks(t.I)) * MT * 16 * H, dt=F32))
         # ---- shared workspaces (launches are stream-ordered)
-        nmax = max(c.vocab_size, t.V, 2 * I, 2 * t.I)
+        nmax = max(c.vocab_size, t.V, 2 * I, 2 * t.I, self.nqkv_d, t.nqkv)
         kmax = max(H, I, t.I, c.fc_in, c.q_dim)
         self.gws = torch.zeros(max(ops.lib().dfl_gemm_batch_ws_bytes(n, k) for n, k in
                                    ((nmax, H), (H, kmax))), dtype=torch.uint8, device=dev)
         # one per model: the arrival tickets sit behind the partials, whose size depends on n_q
         self.aws_d = ops.attn_fused_batch_ws(MT, c.num_attention_heads, c.num_key_value_heads, max_splits, dev)
         self.aws_t = ops.attn_fused_batch_ws(MT, t.n_q, t.n_kv, max_splits, dev)
+        # round 2: the attention stage on finished bf16 q/k/v rows (dfl_attn_head_batch); "fused" keeps the round-1 stage
+        self.attn_impl = getattr(model, "attn_impl", "head")
+        self.hws_d = ops.attn_head_batch_ws(MT, c.num_attention_heads, max_splits, dev)
+        self.hws_t = ops.attn_head_batch_ws(MT, t.n_q, max_splits, dev)
+        self.d["xq"], self.t["xq"] = z(MT, 16, self.nqkv_d), z(MT, 16, t.nqkv)
         # ---- row sources
         # (normalised operands come from dfl_norm_frag_batch: at 4 tiles the in-GEMM norm of the
         # single-request path, replicated in every workgroup, costs more than that launch)
@@ -213,13 +218,22 @@ class BatchedDecoder:
         for i, lw in enumerate(L):
             ops.norm_frag_batch(d["h"], R, lw["ln1"], eps, d["xn"], self.dyn_t, ops.DYN_BS,
                                 part=d["part_h"] if pend else None, N=H, K=pend)
-            ops.gemm_f32_batch(lw["qkv"], s["xn"], R, self.nqkv_d, H, d["part_qkv"], self.dyn_t)
-            ops.attn_fused_batch(qkv=d["part_qkv"], nsplit=nsp, split_stride=MT * 16 * self.nqkv_d, ld=self.nqkv_d,
-                                 q_col=0, k_col=c.q_dim, v_col=c.q_dim + c.kv_dim, R=R, n_q=c.num_attention_heads,
-                                 n_kv=c.num_key_value_heads, q_norm_w=lw["q_norm"], k_norm_w=lw["k_norm"],
-                                 eps=c.rms_norm_eps, cos_tab=cos, sin_tab=sin, kcache=self.dk, vcache=self.dv, layer=i,
-                                 scale=c.head_dim ** -0.5, causal=False, dyn=self.dyn_t, kv_len_max=kvmax,
-                                 ws=self.aws_d, max_splits=self.max_splits, out_frag=d["attn"])
+            if self.attn_impl == "head":
+                ops.gemm_resid_batch(lw["qkv"], s["xn"], R, self.nqkv_d, H, d["xq"], add_residual=False, ws=self.gws,
+                                     dyn=self.dyn_t)
+                ops.attn_head_batch(xq=d["xq"], q_col=0, k_col=c.q_dim, v_col=c.q_dim + c.kv_dim, R=R,
+                                    n_q=c.num_attention_heads, n_kv=c.num_key_value_heads, q_norm_w=lw["q_norm"],
+                                    k_norm_w=lw["k_norm"], eps=c.rms_norm_eps, cos_tab=cos, sin_tab=sin, kcache=self.dk,
+                                    vcache=self.dv, layer=i, scale=c.head_dim ** -0.5, causal=False, dyn=self.dyn_t,
+                                    kv_len_max=kvmax, ws=self.hws_d, max_splits=self.max_splits, out_frag=d["attn"])
+            else:
+                ops.gemm_f32_batch(lw["qkv"], s["xn"], R, self.nqkv_d, H, d["part_qkv"], self.dyn_t)
+                ops.attn_fused_batch(qkv=d["part_qkv"], nsplit=nsp, split_stride=MT * 16 * self.nqkv_d, ld=self.nqkv_d,
+                                     q_col=0, k_col=c.q_dim, v_col=c.q_dim + c.kv_dim, R=R, n_q=c.num_attention_heads,
+                                     n_kv=c.num_key_value_heads, q_norm_w=lw["q_norm"], k_norm_w=lw["k_norm"],
+                                     eps=c.rms_norm_eps, cos_tab=cos, sin_tab=sin, kcache=self.dk, vcache=self.dv,
+                                     layer=i, scale=c.head_dim ** -0.5, causal=False, dyn=self.dyn_t, kv_len_max=kvmax,
+                                     ws=self.aws_d, max_splits=self.max_splits, out_frag=d["attn"])
             ops.gemm_f32_batch(lw["o"], s["attn"], R, H, c.q_dim, d["part_h"], self.dyn_t)
             ops.norm_frag_batch(d["h"], R, lw["ln2"], eps, d["xn"], self.dyn_t, ops.DYN_BS, part=d["part_h"], N=H,
                                 K=c.q_dim)
@@ -259,13 +273,22 @@ class BatchedDecoder:
             ops.norm_frag_batch(tt["h"], R, lw["ln1"], t.eps, tt["xn"], self.dyn_t, ops.DYN_BS,
                                 part=tt["part_h"] if pend else None, N=H, K=pend, tap=ptap)
             spread(pdup)
-            ops.gemm_f32_batch(lw["qkv"], s["xn"], R, t.nqkv, H, tt["part_qkv"], self.dyn_t)
-            ops.attn_fused_batch(qkv=tt["part_qkv"], nsplit=nsp, split_stride=MT * 16 * t.nqkv, ld=t.nqkv, q_col=0,
-                                 k_col=t.q_dim, v_col=t.q_dim + t.kv_dim, R=R, n_q=t.n_q, n_kv=t.n_kv,
-                                 q_norm_w=lw["q_norm"], k_norm_w=lw["k_norm"], eps=t.eps, cos_tab=cos, sin_tab=sin,
-                                 kcache=self.tk, vcache=self.tv, layer=i, scale=128 ** -0.5, causal=True,
-                                 dyn=self.dyn_t, kv_len_max=kvmax, ws=self.aws_t, max_splits=self.max_splits,
-                                 out_frag=tt["attn"])
+            if self.attn_impl == "head":
+                ops.gemm_resid_batch(lw["qkv"], s["xn"], R, t.nqkv, H, tt["xq"], add_residual=False, ws=self.gws,
+                                     dyn=self.dyn_t)
+                ops.attn_head_batch(xq=tt["xq"], q_col=0, k_col=t.q_dim, v_col=t.q_dim + t.kv_dim, R=R, n_q=t.n_q,
+                                    n_kv=t.n_kv, q_norm_w=lw["q_norm"], k_norm_w=lw["k_norm"], eps=t.eps, cos_tab=cos,
+                                    sin_tab=sin, kcache=self.tk, vcache=self.tv, layer=i, scale=128 ** -0.5, causal=True,
+                                    dyn=self.dyn_t, kv_len_max=kvmax, ws=self.hws_t, max_splits=self.max_splits,
+                                    out_frag=tt["attn"])
+            else:
+                ops.gemm_f32_batch(lw["qkv"], s["xn"], R, t.nqkv, H, tt["part_qkv"], self.dyn_t)
+                ops.attn_fused_batch(qkv=tt["part_qkv"], nsplit=nsp, split_stride=MT * 16 * t.nqkv, ld=t.nqkv, q_col=0,
+                                     k_col=t.q_dim, v_col=t.q_dim + t.kv_dim, R=R, n_q=t.n_q, n_kv=t.n_kv,
+                                     q_norm_w=lw["q_norm"], k_norm_w=lw["k_norm"], eps=t.eps, cos_tab=cos, sin_tab=sin,
+                                     kcache=self.tk, vcache=self.tv, layer=i, scale=128 ** -0.5, causal=True,
+                                     dyn=self.dyn_t, kv_len_max=kvmax, ws=self.aws_t,
+                                     max_splits=self.max_splits, out_frag=tt["attn"])
             ops.gemm_f32_batch(lw["o"], s["attn"], R, H, t.q_dim, tt["part_h"], self.dyn_t)
             ops.norm_frag_batch(tt["h"], R, lw["ln2"], t.eps, tt["xn"], self.dyn_t, ops.DYN_BS, part=tt["part_h"],
                                 N=H, K=t.q_dim)

@@ -64,7 +64,10 @@ struct HeadAttnArgs {
   // prefix): candidate c reads its block rows at xq + c * xq_cand_stride, writes its frag16 output at
   // out_frag + c * out_cand_stride, its partials / tickets at + c * ws_cand_stride floats, and its NEW K/V rows
   // not into the cache but into kv_out rows [0, bs): [c][n_kv][out_rows][128] — the caller copies the winner's.
-  int64_t xq_cand_stride, out_cand_stride, ws_cand_stride;
+  // The same dimension carries the REQUESTS of a ragged batch (dfl_attn_head_batch): then every request also has its
+  // own length record (dyn + c * dyn_cand_stride ints) and its own cache (+ c * cache_cand_stride elements).
+  int64_t xq_cand_stride, out_cand_stride, ws_cand_stride, cache_cand_stride;
+  int dyn_cand_stride;
   bf16_t *k_out, *v_out;   // null: the new rows go to the cache at rows S + rel
   int64_t kv_out_cand_stride;
   int out_rows;
@@ -220,30 +223,32 @@ __global__ __launch_bounds__(512) void k_attn_head(HeadAttnArgs a) {
   const int head = kvh * a.G + hh;
   const int ns = a.ns_old + 1;
   const bool is_new = split == a.ns_old;
+  const int cand = blockIdx.z;  // candidate of a multi-candidate verify / request of a ragged batch (0 otherwise)
   int S = a.S, tau = a.tau, bs = a.bs, pos0 = a.pos0;
   if (a.dyn) {
-    S = a.dyn[DFL_DYN_S];
-    tau = a.dyn[DFL_DYN_TAU];
-    bs = a.dyn[DFL_DYN_BS];
-    pos0 = a.dyn[DFL_DYN_POS0];
+    const int32_t *dp = a.dyn + cand * a.dyn_cand_stride;
+    S = dp[DFL_DYN_S];
+    tau = dp[DFL_DYN_TAU];
+    bs = dp[DFL_DYN_BS];
+    pos0 = dp[DFL_DYN_POS0];
   }
   const int n_new = tau + bs;  // <= 64
   const int qi = l & 15, g = l >> 4;
   HSTAMP(0);
-  // candidate c of a multi-candidate verify (grid.z; 0 otherwise): plain locals, the argument block stays untouched
-  const int cand = blockIdx.z;
+  // per-candidate / per-request views as plain locals: the argument block stays untouched
   const bf16_t *const xq = a.xq + cand * a.xq_cand_stride;
   bf16x8 *const out_frag = a.out_frag + cand * a.out_cand_stride;
   float *const o_part = a.o_part + cand * a.ws_cand_stride;
   float *const ml_part = a.ml_part + cand * a.ws_cand_stride;
   int *const tickets = a.tickets + cand * a.ws_cand_stride;
-  bf16_t *const k_new = a.k_out ? a.k_out + cand * a.kv_out_cand_stride : a.kc;
-  bf16_t *const v_new = a.k_out ? a.v_out + cand * a.kv_out_cand_stride : a.vc;
+  bf16_t *const kc = a.kc + cand * a.cache_cand_stride, *const vc = a.vc + cand * a.cache_cand_stride;
+  bf16_t *const k_new = a.k_out ? a.k_out + cand * a.kv_out_cand_stride : kc;
+  bf16_t *const v_new = a.k_out ? a.v_out + cand * a.kv_out_cand_stride : vc;
   const int new_rows_cap = a.k_out ? a.out_rows : a.cache_rows;
   const int new_row0 = a.k_out ? 0 : S;
+  const bf16_t *kbase = kc + (int64_t)kvh * a.cache_rows * 128;
+  const bf16_t *vbase = vc + (int64_t)kvh * a.cache_rows * 128;
 
-  const bf16_t *kbase = a.kc + (int64_t)kvh * a.cache_rows * 128;
-  const bf16_t *vbase = a.vc + (int64_t)kvh * a.cache_rows * 128;
 
   // ---- old-key tiles of this split; wave w walks t0 + w, t0 + w + 8, ...
   int t0 = 0, t1 = 0;
@@ -628,7 +633,7 @@ int attn_head_launch(const void *xq, int64_t ldq, int q_col, int k_col, int v_co
                      float scale, int causal, const int32_t *dyn, int S, int tau, int bs, int pos0, int q_tiles, void *ws,
                      int max_splits, void *out_frag, int64_t out_tile_stride, int n_cand, int64_t xq_cand_stride,
                      int64_t out_cand_stride, void *k_out, void *v_out, int64_t kv_out_cand_stride, int out_rows,
-                     void *stream) {
+                     int dyn_cand_stride, int64_t cache_cand_stride, void *stream) {
   DFL_REQUIRE(xq && cos_tab && sin_tab && kcache && vcache && out_frag && ws, "dfl_attn_head: null pointer");
   DFL_REQUIRE((q_norm_w == nullptr) == (k_norm_w == nullptr), "dfl_attn_head: give both norm weights or neither");
   DFL_REQUIRE(n_q > 0 && n_kv > 0 && n_q % n_kv == 0, "dfl_attn_head: bad head counts (n_q=%d n_kv=%d)", n_q, n_kv);
@@ -644,8 +649,10 @@ int attn_head_launch(const void *xq, int64_t ldq, int q_col, int k_col, int v_co
               cache_rows);
   DFL_REQUIRE(max_splits >= 1 && out_tile_stride >= 0 && out_tile_stride % 8 == 0, "dfl_attn_head: bad max_splits / out_tile_stride");
   DFL_REQUIRE(n_cand >= 1 && n_cand <= 64, "dfl_attn_head: n_cand outside 1..64");
-  DFL_REQUIRE(n_cand == 1 || (xq_cand_stride % 8 == 0 && out_cand_stride % 8 == 0 && k_out && v_out),
-              "dfl_attn_head: candidates need 8-element strides and a K/V staging area (they must not write the cache)");
+  DFL_REQUIRE(n_cand == 1 || (xq_cand_stride % 8 == 0 && out_cand_stride % 8 == 0 && cache_cand_stride % 8 == 0 &&
+                              ((k_out && v_out) || cache_cand_stride >= (int64_t)n_kv * cache_rows * 128)),
+              "dfl_attn_head: several blocks per launch need 8-element strides and either a K/V staging area "
+              "(candidates on one cache) or a cache per request");
   DFL_REQUIRE(!k_out == !v_out && (!k_out || (out_rows >= tau + bs && kv_out_cand_stride >= (int64_t)n_kv * out_rows * 128)),
               "dfl_attn_head: bad K/V staging area");
   // Old-key splits: a workgroup's 8 waves take one 32-key tile each per round, so up to 8 tiles
@@ -659,7 +666,8 @@ int attn_head_launch(const void *xq, int64_t ldq, int q_col, int k_col, int v_co
   static const int knob_wgs = [] { const char *e = getenv("DFL_ATTN_HEAD_WGS"); return e ? atoi(e) : 224; }();
   const int tiles = knob_tiles < 1 ? 1 : knob_tiles;
   int ns_old = (nt + tiles - 1) / tiles;
-  int budget = knob_wgs / (n_q * n_cand) - 1;
+  // (several blocks per launch: up to two rounds of workgroups, or every block would be left with one split)
+  int budget = knob_wgs * (n_cand > 1 ? 2 : 1) / (n_q * n_cand) - 1;
   budget = budget < 1 ? 1 : budget;
   ns_old = ns_old > budget ? budget : ns_old;
   ns_old = ns_old > max_splits - 1 ? max_splits - 1 : ns_old;
@@ -707,6 +715,8 @@ int attn_head_launch(const void *xq, int64_t ldq, int q_col, int k_col, int v_co
   a.v_out = (bf16_t *)v_out;
   a.kv_out_cand_stride = kv_out_cand_stride;
   a.out_rows = out_rows;
+  a.dyn_cand_stride = dyn_cand_stride;
+  a.cache_cand_stride = cache_cand_stride;
   const dim3 grid(n_kv, G * (ns_old + 1), n_cand);
   hipStream_t st = (hipStream_t)stream;
   if (q_tiles == 1)
@@ -726,7 +736,7 @@ extern "C" int dfl_attn_head(const void *xq, int64_t ldq, int q_col, int k_col, 
                              int64_t out_tile_stride, void *stream) {
   return attn_head_launch(xq, ldq, q_col, k_col, v_col, xc, ldc, ck_col, cv_col, n_q, n_kv, q_norm_w, k_norm_w, eps, cos_tab,
                           sin_tab, max_pos, kcache, vcache, cache_rows, scale, causal, dyn, S, tau, bs, pos0, q_tiles, ws,
-                          max_splits, out_frag, out_tile_stride, 1, 0, 0, nullptr, nullptr, 0, 0, stream);
+                          max_splits, out_frag, out_tile_stride, 1, 0, 0, nullptr, nullptr, 0, 0, 0, 0, stream);
 }
 
 extern "C" int dfl_attn_head_cand(const void *xq, int64_t ldq, int q_col, int k_col, int v_col, int n_cand,
@@ -739,5 +749,20 @@ extern "C" int dfl_attn_head_cand(const void *xq, int64_t ldq, int q_col, int k_
   return attn_head_launch(xq, ldq, q_col, k_col, v_col, nullptr, 0, 0, 0, n_q, n_kv, q_norm_w, k_norm_w, eps, cos_tab, sin_tab,
                           max_pos, const_cast<void *>(kcache), const_cast<void *>(vcache), cache_rows, scale, 1, nullptr, S, 0,
                           bs, S, 1, ws, max_splits, out_frag, 0, n_cand, xq_cand_stride, out_cand_stride, k_out, v_out,
-                          kv_out_cand_stride, out_rows, stream);
+                          kv_out_cand_stride, out_rows, 0, 0, stream);
+}
+
+extern "C" int dfl_attn_head_batch(const void *xq, int64_t ldq, int q_col, int k_col, int v_col, int R, int64_t xq_req_stride,
+                                   int n_q, int n_kv, const void *q_norm_w, const void *k_norm_w, float eps,
+                                   const void *cos_tab, const void *sin_tab, int max_pos, void *kcache, void *vcache,
+                                   int cache_rows, int64_t cache_req_stride, float scale, int causal, const int32_t *dyn,
+                                   int kv_len_max, void *ws, int max_splits, void *out_frag, int64_t out_req_stride,
+                                   void *stream) {
+  DFL_REQUIRE(dyn, "dfl_attn_head_batch: the requests' lengths come from dyn (R records)");
+  DFL_REQUIRE(kv_len_max >= 16 && kv_len_max <= cache_rows, "dfl_attn_head_batch: kv_len_max=%d outside 16..cache_rows", kv_len_max);
+  // lengths from the device records (block form: tau = 0, bs <= 16); kv_len_max - 16 bounds every request's S
+  return attn_head_launch(xq, ldq, q_col, k_col, v_col, nullptr, 0, 0, 0, n_q, n_kv, q_norm_w, k_norm_w, eps, cos_tab, sin_tab,
+                          max_pos, kcache, vcache, cache_rows, scale, causal, dyn, kv_len_max - 16, 0, 16, 0, 1, ws, max_splits,
+                          out_frag, 0, R, xq_req_stride, out_req_stride, nullptr, nullptr, 0, 0, DFL_DYN_WORDS, cache_req_stride,
+                          stream);
 }

@@ -298,6 +298,26 @@ def attn_head_cand(*, xq: torch.Tensor, q_col: int, k_col: int, v_col: int, n_q:
         "dfl_attn_head_cand")
 
 
+def attn_head_batch_ws(R: int, n_q: int, max_splits: int, device) -> torch.Tensor:
+    return torch.zeros(R * lib().dfl_attn_head_ws_bytes(n_q, max_splits, 1), dtype=torch.uint8, device=device)
+
+
+def attn_head_batch(*, xq: torch.Tensor, q_col: int, k_col: int, v_col: int, R: int, n_q: int, n_kv: int, q_norm_w,
+                    k_norm_w, eps, cos_tab, sin_tab, kcache, vcache, layer: int, scale: float, causal: bool, dyn,
+                    kv_len_max: int, ws, max_splits: int, out_frag: torch.Tensor) -> None:
+    """xq [MT, 16, ldq] bf16; kcache/vcache [MT, L, n_kv, rows, 128] (layer `layer` is used); out_frag [MT, 16*n_q*128]."""
+    assert xq.is_cuda and xq.dtype == BF16 and xq.dim() == 3 and xq.stride(2) == 1
+    assert kcache.shape == vcache.shape and kcache.dim() == 5 and kcache.shape[4] == 128 and kcache.is_contiguous()
+    assert out_frag.dim() == 2 and out_frag.is_contiguous()
+    kc, vc = kcache[0, layer], vcache[0, layer]
+    check(lib().dfl_attn_head_batch(
+        xq.data_ptr(), xq.stride(1), q_col, k_col, v_col, R, xq.stride(0), n_q, n_kv, _p(q_norm_w, BF16, "q_norm_w"),
+        _p(k_norm_w, BF16, "k_norm_w"), eps, _p(cos_tab, BF16, "cos"), _p(sin_tab, BF16, "sin"), cos_tab.shape[0],
+        kc.data_ptr(), vc.data_ptr(), kcache.shape[3], kcache.stride(0), scale, int(causal), _p(dyn, I32, "dyn"),
+        kv_len_max, _p(ws), max_splits, _p(out_frag, BF16, "out_frag"), out_frag.stride(0), _stream()),
+        "dfl_attn_head_batch")
+
+
 def topk_rows(logits: torch.Tensor, k: int):
     """logits bf16 [rows, V] (unit inner stride) -> (values fp32 [rows, 8], indices int32 [rows, 8], lse fp32 [rows]);
     columns >= k are unspecified.  Order: value descending, index ascending."""

@@ -242,6 +242,17 @@ int dfl_attn_head_cand(const void *xq, int64_t ldq, int q_col, int k_col, int v_
                        float scale, int S, int bs, void *ws, int max_splits, void *out_frag, int64_t out_cand_stride,
                        void *k_out, void *v_out, int64_t kv_out_cand_stride, int out_rows, void *stream);
 
+/* dfl_attn_head for the R requests of a ragged batch in one launch (grid.z = request; replaces dfl_attn_fused_batch):
+ * request r's block rows at xq + r * xq_req_stride, its lengths at dyn + r * DFL_DYN_WORDS (block form: the context rows
+ * are cached already, dyn tau == 0), its cache at + r * cache_req_stride, its frag16 output at + r * out_req_stride.
+ * kv_len_max bounds S + 16 over the requests (it sizes the key splits).  ws: R * dfl_attn_head_ws_bytes(n_q, max_splits,
+ * 1) bytes, zeroed once. */
+int dfl_attn_head_batch(const void *xq, int64_t ldq, int q_col, int k_col, int v_col, int R, int64_t xq_req_stride, int n_q,
+                        int n_kv, const void *q_norm_w, const void *k_norm_w, float eps, const void *cos_tab,
+                        const void *sin_tab, int max_pos, void *kcache, void *vcache, int cache_rows,
+                        int64_t cache_req_stride, float scale, int causal, const int32_t *dyn, int kv_len_max, void *ws,
+                        int max_splits, void *out_frag, int64_t out_req_stride, void *stream);
+
 /* Per row of bf16 logits [rows][ld] (rows <= 64): the k <= 8 largest values with their indices, ordered (value
  * descending, index ascending) — out_val fp32 [rows][8], out_idx int32 [rows][8] — and the row's log-sum-exp (fp32).
  * What the candidate builders take from the 15 x V draft logits: torch.topk at :216, :296, the top-2 probability
