@@ -50,6 +50,8 @@ class BatchedDecoder:
                  temperature: float = 0.0):
         if not isinstance(target, NativeTarget):
             raise TypeError("BatchedDecoder needs a dflash_amd.NativeTarget (see module docstring)")
+        if getattr(target, "is_moe", False):
+            raise NotImplementedError("the ragged batch runs dense targets; an MoE target decodes one request at a time")
         if not 1 <= n_requests <= MAX_GROUP:
             raise ValueError(f"a group holds 1..{MAX_GROUP} requests")
         if model.w is None:

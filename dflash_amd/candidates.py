@@ -211,6 +211,8 @@ class NativeCandidateVerifier:
         from .target import NativeTarget
         if not isinstance(target, NativeTarget):
             raise TypeError("NativeCandidateVerifier needs a dflash_amd.NativeTarget")
+        if getattr(target, "is_moe", False):
+            raise NotImplementedError("the one-pass candidate verify runs dense targets")
         t, MT = target, self.MT
         self.t, self.max_splits = t, max_splits
         dev = t.device

@@ -1,0 +1,195 @@
+// Sparse-MoE MLP of the target's verify forward (BASELINE configs[4]: Qwen3-Coder-30B-A3B; the reference calls the HF
+// model, model/dflash.py:249-255; arithmetic: tf:models/qwen3_moe/modeling_qwen3_moe.py — Qwen3MoeTopKRouter.forward,
+// Qwen3MoeExperts.forward).  For the <= 16 block rows of a verify:
+//   k_moe_route   router logits [16][E] (bf16, the gate Linear's output) -> fp32 softmax -> top-k -> normalised bf16
+//                 weights as a dense [16][E] matrix (0 = not routed), the ascending list of experts some row uses
+//   (dfl_gemm_silu_mul_experts, gemm_skinny.hip: act_e = silu(x Wg_e^T) * (x Wu_e^T) for every active expert)
+//   k_moe_down    out[m][n] = sum over active experts e of w[m][e] * (act_e[m] . Wd_e[n]) as fp32 K-part sums: one MFMA
+//                 tile of 16 output columns per workgroup, the active experts dealt to its 16 waves, each wave scaling
+//                 its expert's 16x16 product by the rows' routing weights before it adds it up.
+// Rounding: HF rounds every expert's down-projection to bf16, scales it in bf16 and accumulates the <= k terms of a
+// row in bf16 (index_add_ in expert order); here the sum over experts stays in fp32 and is rounded once, where the
+// dense MLP's Linear output is rounded — fewer roundings than the reference, inside the stated bf16 tolerance.
+#include "gemm_rows.h"
+
+namespace {
+
+__device__ __forceinline__ bool route_better(float v, int i, float ov, int oi) { return v > ov || (v == ov && i < oi); }
+
+// one wavefront per row (16 rows), E <= 256
+__global__ __launch_bounds__(1024) void k_moe_route(const bf16_t *logits, int ld, int E, int top_k, int norm_topk,
+                                                    bf16_t *wt, int32_t *active, int32_t *list, int32_t *n_active,
+                                                    const int32_t *dyn, int dyn_word) {
+  const int tid = threadIdx.x, m = tid >> 6, l = tid & 63;
+  const int nv = dyn ? dyn[dyn_word] : 16;
+  for (int e = tid; e < E; e += 1024) active[e] = 0;
+  __syncthreads();
+  float p[4];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = l + 64 * j;
+    p[j] = e < E ? bf2f(logits[(int64_t)m * ld + e]) : -INFINITY;
+    mx = fmaxf(mx, p[j]);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    p[j] = (l + 64 * j) < E ? __expf(p[j] - mx) : 0.f;
+    sum += p[j];
+  }
+  sum = wave_sum(sum);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    p[j] = p[j] / sum;  // softmax(dtype = float), Qwen3MoeTopKRouter.forward
+    const int e = l + 64 * j;
+    if (e < E) wt[(int64_t)m * E + e] = (bf16_t)0.f;
+  }
+  // top-k: k rounds of a wave argmax, (probability desc, expert index asc)
+  float sel_v[8];
+  int sel_i[8];
+  float tot = 0.f;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {   // unrolled with a guard: a runtime index would send sel_v / sel_i to scratch memory
+    if (r >= top_k) break;
+    float bv = -1.f;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = l + 64 * j;
+      if (e < E && route_better(p[j], e, bv, bi)) {
+        bv = p[j];
+        bi = e;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (route_better(ov, oi, bv, bi)) {
+        bv = ov;
+        bi = oi;
+      }
+    }
+    sel_v[r] = bv;
+    sel_i[r] = bi;
+    tot += bv;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (l + 64 * j == bi) p[j] = -1.f;  // taken
+  }
+  if (m < nv && l == 0) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      if (r < top_k) {
+        const float w = norm_topk ? sel_v[r] / tot : sel_v[r];
+        wt[(int64_t)m * E + sel_i[r]] = f2bf(w);
+        active[sel_i[r]] = 1;
+      }
+    }
+  }
+  __syncthreads();
+  // ascending list of the active experts (wave 0)
+  if (m == 0) {
+    int base = 0;
+    for (int e0 = 0; e0 < E; e0 += 64) {
+      const int e = e0 + l;
+      const bool a = e < E && active[e] != 0;
+      const unsigned long long b = __ballot(a);
+      if (a) list[base + __popcll(b & ((1ull << l) - 1ull))] = e;
+      base += __popcll(b);
+    }
+    if (l == 0) *n_active = base;
+  }
+}
+
+struct MoeDownArgs {
+  const bf16x8 *wd;     // [E][ntiles][KSe][64]
+  int64_t wd_stride;    // bf16x8 units per expert
+  const bf16x8 *act;    // [E] frag16 [KSe][64]
+  int64_t act_stride;   // bf16x8 units per expert
+  const bf16_t *wt;     // [16][E]
+  const int32_t *list, *n_active;
+  int E, KSe, ntiles;
+  float *out;           // [nsplit][16][ldo]
+  int ldo;
+};
+
+__global__ __launch_bounds__(1024) void k_moe_down(MoeDownArgs a) {
+  __shared__ float red[16][256];
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
+  const int t = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
+  const int n = *a.n_active;
+  const int per = (n + nsplit - 1) / nsplit;
+  const int p0 = split * per, p1 = min(n, p0 + per);
+  f32x4 total = {0.f, 0.f, 0.f, 0.f};
+  for (int p = p0 + w; p < p1; p += 16) {
+    const int e = a.list[p];
+    const float wr = bf2f(a.wt[(int64_t)(l & 15) * a.E + e]);  // the routing weight of this lane's row
+    const bf16x8 *wbase = a.wd + e * a.wd_stride + (size_t)t * a.KSe * 64;
+    const bf16x8 *xbase = a.act + e * a.act_stride;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int ks0 = 0; ks0 < a.KSe; ks0 += 8) {
+      int nf = a.KSe - ks0;
+      nf = nf > 8 ? 8 : nf;
+      bf16x8 wv[8], xv[8];
+      load_ksteps<8>(wv, wbase + (size_t)ks0 * 64, nf, l);
+      load_ksteps<8>(xv, xbase + (size_t)ks0 * 64, nf, l);  // past nf: zero fragments on both sides
+#pragma unroll
+      for (int f = 0; f < 8; ++f) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[f], xv[f], acc, 0, 0, 0);
+    }
+    // D layout: lane L, register r = output column 4 (L >> 4) + r of row L & 15
+    total += acc * wr;
+  }
+  *reinterpret_cast<f32x4 *>(&red[w][l * 4]) = total;
+  __syncthreads();
+  if (tid < 256) {
+    const int m = tid >> 4, nl = tid & 15;
+    const int idx = 4 * (m + 16 * (nl >> 2)) + (nl & 3);
+    float s = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < 16; ++ww) s += red[ww][idx];
+    a.out[((size_t)split * 16 + m) * a.ldo + t * 16 + nl] = s;
+  }
+}
+
+}  // namespace
+
+extern "C" int dfl_moe_route(const void *logits, int ld, int E, int top_k, int norm_topk, void *wt, int32_t *active,
+                             int32_t *list, int32_t *n_active, const int32_t *dyn, int dyn_word, void *stream) {
+  DFL_REQUIRE(logits && wt && active && list && n_active, "dfl_moe_route: null pointer");
+  DFL_REQUIRE(E >= 1 && E <= 256 && ld >= E && top_k >= 1 && top_k <= 8 && top_k <= E, "dfl_moe_route: E=%d top_k=%d outside range",
+              E, top_k);
+  hipLaunchKernelGGL(k_moe_route, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const bf16_t *)logits, ld, E, top_k,
+                     norm_topk ? 1 : 0, (bf16_t *)wt, active, list, n_active, dyn, dyn_word);
+  DFL_CHECK_LAUNCH("dfl_moe_route");
+  return DFL_OK;
+}
+
+extern "C" int dfl_moe_down(const void *wp_down, int64_t wp_expert_stride, const void *act_frag, int64_t act_expert_stride,
+                            const void *wt, const int32_t *list, const int32_t *n_active, int E, int N, int I, int nsplit,
+                            float *out, void *stream) {
+  DFL_REQUIRE(wp_down && act_frag && wt && list && n_active && out, "dfl_moe_down: null pointer");
+  DFL_REQUIRE(E >= 1 && N > 0 && I > 0 && N % 16 == 0 && I % 32 == 0 && nsplit >= 1 && nsplit <= 16, "dfl_moe_down: bad shape");
+  DFL_REQUIRE(wp_expert_stride >= (int64_t)N * I && wp_expert_stride % 8 == 0 && act_expert_stride >= (int64_t)16 * I &&
+                  act_expert_stride % 8 == 0,
+              "dfl_moe_down: expert strides too short");
+  MoeDownArgs a{};
+  a.wd = (const bf16x8 *)wp_down;
+  a.wd_stride = wp_expert_stride / 8;
+  a.act = (const bf16x8 *)act_frag;
+  a.act_stride = act_expert_stride / 8;
+  a.wt = (const bf16_t *)wt;
+  a.list = list;
+  a.n_active = n_active;
+  a.E = E;
+  a.KSe = I / 32;
+  a.ntiles = N / 16;
+  a.out = out;
+  a.ldo = N;
+  hipLaunchKernelGGL(k_moe_down, dim3(N / 16, nsplit), dim3(1024), 0, (hipStream_t)stream, a);
+  DFL_CHECK_LAUNCH("dfl_moe_down");
+  return DFL_OK;
+}

@@ -344,6 +344,36 @@ def candidate_select(blocks: torch.Tensor, posterior: torch.Tensor, scores: torc
         _stream()), "dfl_candidate_select")
 
 
+# ---- sparse-MoE MLP of a target verify (include/dflash_hip.h, moe section) ----------------------------------------
+def moe_route(logits: torch.Tensor, E: int, top_k: int, norm_topk: bool, wt: torch.Tensor, active: torch.Tensor,
+              lst: torch.Tensor, n_active: torch.Tensor, dyn=None, dyn_word: int = 0) -> None:
+    """logits bf16 [16, >= E]; wt bf16 [16, E]; active / lst int32 [E]; n_active int32 [1]."""
+    assert logits.dtype == BF16 and logits.dim() == 2 and logits.stride(1) == 1 and logits.shape[0] >= 16
+    assert wt.dtype == BF16 and wt.is_contiguous() and wt.numel() >= 16 * E
+    check(lib().dfl_moe_route(logits.data_ptr(), logits.stride(0), E, top_k, int(norm_topk), _p(wt), _p(active, I32, "active"),
+                              _p(lst, I32, "list"), _p(n_active, I32, "n_active"), _p(dyn, I32, "dyn"), dyn_word,
+                              _stream()), "dfl_moe_route")
+
+
+def gemm_silu_mul_experts(wp_gu: torch.Tensor, x, E: int, I: int, K: int, act: torch.Tensor, active: torch.Tensor,
+                          dyn=None) -> None:
+    """wp_gu bf16 [E, 2*I*K] packed per expert; act bf16 [E, 16*I] (frag16 per expert)."""
+    assert wp_gu.dim() == 2 and wp_gu.is_contiguous() and act.dim() == 2 and act.is_contiguous()
+    check(lib().dfl_gemm_silu_mul_experts(_p(wp_gu, BF16, "wp_gu"), wp_gu.stride(0), _src(x).ref, E, I, K,
+                                          _p(act, BF16, "act"), act.stride(0), _p(active, I32, "active"),
+                                          _p(dyn, I32, "dyn"), _stream()), "dfl_gemm_silu_mul_experts")
+
+
+def moe_down(wp_down: torch.Tensor, act: torch.Tensor, wt: torch.Tensor, lst: torch.Tensor, n_active: torch.Tensor, E: int,
+             N: int, I: int, nsplit: int, out: torch.Tensor) -> None:
+    """wp_down bf16 [E, N*I] packed per expert; out fp32 [nsplit, 16, N]."""
+    assert wp_down.dim() == 2 and wp_down.is_contiguous() and act.dim() == 2 and act.is_contiguous()
+    assert out.dtype == F32 and out.is_contiguous() and out.numel() >= nsplit * 16 * N
+    check(lib().dfl_moe_down(_p(wp_down, BF16, "wp_down"), wp_down.stride(0), _p(act, BF16, "act"), act.stride(0),
+                             _p(wt, BF16, "wt"), _p(lst, I32, "list"), _p(n_active, I32, "n_active"), E, N, I, nsplit,
+                             _p(out, F32, "out"), _stream()), "dfl_moe_down")
+
+
 def argmax(logits: torch.Tensor) -> torch.Tensor:
     """First-max-index argmax over the last axis, int64 (model/utils.py:28-29)."""
     if logits.dtype not in (BF16, F32):

@@ -79,7 +79,10 @@ def impose_greedy_walk(hf_model, seed: int = 1234) -> torch.Tensor:
         del emb
         for layer in hf_model.model.layers:
             layer.self_attn.o_proj.weight.mul_(0.02)
-            layer.mlp.down_proj.weight.mul_(0.02)
+            if hasattr(layer.mlp, "experts"):      # sparse-MoE layer: the experts' fused down projections
+                layer.mlp.experts.down_proj.mul_(0.02)
+            else:
+                layer.mlp.down_proj.weight.mul_(0.02)
     return perm
 
 

@@ -77,15 +77,24 @@ class NativeTarget:
         rope = getattr(cfg, "rope_parameters", None) or {}
         rtype = rope.get("rope_type", "default") if isinstance(rope, dict) else "default"
         theta = (rope.get("rope_theta") if isinstance(rope, dict) else None) or getattr(cfg, "rope_theta", None)
-        if self.hd != 128 or self.H // 32 > 128 or self.H % 32 or self.I % 32 or self.V % 16:
+        if self.hd != 128 or self.H // 32 > 128 or self.H % 32 or (self.I % 32 and not getattr(cfg, "num_experts", 0)) or self.V % 16:
             raise NotImplementedError("NativeTarget: needs head_dim 128, hidden <= 4096 (%32), vocab %16")
         # position-only RoPE variants: the cos/sin tables are taken from the wrapped model's own
         # rotary module (Llama-3.1's "llama3" frequency scaling, BASELINE config 4; linear; yarn)
         if rtype not in ("default", "llama3", "linear", "yarn") or (rtype == "default" and theta is None):
             raise NotImplementedError(f"NativeTarget: rope_type {rtype!r} is not supported; keep the HF target")
         self.rope_type = rtype
-        if getattr(cfg, "num_experts", 0) or getattr(cfg, "num_local_experts", 0):
-            raise NotImplementedError("NativeTarget: MoE targets stay on the HF path")
+        # sparse-MoE targets (BASELINE configs[4], Qwen3-Coder-30B-A3B): HF Qwen3-MoE layout (fused per-expert
+        # gate_up_proj / down_proj tensors, softmax -> top-k -> renormalise router)
+        self.E = int(getattr(cfg, "num_experts", 0) or 0)
+        if getattr(cfg, "num_local_experts", 0) and not self.E:
+            raise NotImplementedError("NativeTarget: only the Qwen3-MoE expert layout is supported; keep the HF target")
+        if self.E:
+            self.top_k = int(cfg.num_experts_per_tok)
+            self.Ie = int(cfg.moe_intermediate_size)
+            self.norm_topk = bool(getattr(cfg, "norm_topk_prob", False))
+            if self.E > 256 or self.top_k > 8 or self.Ie % 32:
+                raise NotImplementedError("NativeTarget: MoE needs <= 256 experts, top-k <= 8, moe_intermediate_size % 32 == 0")
         if getattr(cfg, "attention_bias", False) or getattr(cfg, "mlp_bias", False):
             raise NotImplementedError("NativeTarget: biased projections are not supported")
         self.theta = float(theta) if theta is not None else None
@@ -100,13 +109,27 @@ class NativeTarget:
             qkv = torch.cat([w(p + "self_attn.q_proj.weight"), w(p + "self_attn.k_proj.weight"),
                              w(p + "self_attn.v_proj.weight")], dim=0)
             has_qk = (p + "self_attn.q_norm.weight") in sd
-            self.layers.append({
-                "qkv": ops.pack_weight(qkv), "o": ops.pack_weight(w(p + "self_attn.o_proj.weight")),
-                "gu": ops.pack_weight_gateup(w(p + "mlp.gate_proj.weight"), w(p + "mlp.up_proj.weight")),
-                "down": ops.pack_weight(w(p + "mlp.down_proj.weight")),
-                "q_norm": w(p + "self_attn.q_norm.weight") if has_qk else None,
-                "k_norm": w(p + "self_attn.k_norm.weight") if has_qk else None,
-                "ln1": w(p + "input_layernorm.weight"), "ln2": w(p + "post_attention_layernorm.weight")})
+            lw = {"qkv": ops.pack_weight(qkv), "o": ops.pack_weight(w(p + "self_attn.o_proj.weight")),
+                  "q_norm": w(p + "self_attn.q_norm.weight") if has_qk else None,
+                  "k_norm": w(p + "self_attn.k_norm.weight") if has_qk else None,
+                  "ln1": w(p + "input_layernorm.weight"), "ln2": w(p + "post_attention_layernorm.weight")}
+            if (p + "mlp.experts.gate_up_proj") in sd:       # sparse-MoE layer
+                gup, dwn = w(p + "mlp.experts.gate_up_proj"), w(p + "mlp.experts.down_proj")   # [E, 2I, H], [E, H, I]
+                Ie = self.Ie
+                if gup.shape != (self.E, 2 * Ie, self.H) or dwn.shape != (self.E, self.H, Ie):
+                    raise ValueError(f"layer {i}: unexpected expert tensor shapes {tuple(gup.shape)} {tuple(dwn.shape)}")
+                lw["gu_e"] = torch.stack([ops.pack_weight_gateup(gup[e, :Ie].contiguous(), gup[e, Ie:].contiguous())
+                                          for e in range(self.E)])
+                lw["down_e"] = torch.stack([ops.pack_weight(dwn[e].contiguous()) for e in range(self.E)])
+                ep = (self.E + 15) // 16 * 16               # router rows padded to whole column tiles (never routed to)
+                rw = torch.zeros(ep, self.H, dtype=BF16, device=dev)
+                rw[:self.E] = w(p + "mlp.gate.weight")
+                lw["router"] = ops.pack_weight(rw)
+                del gup, dwn, rw
+            else:
+                lw["gu"] = ops.pack_weight_gateup(w(p + "mlp.gate_proj.weight"), w(p + "mlp.up_proj.weight"))
+                lw["down"] = ops.pack_weight(w(p + "mlp.down_proj.weight"))
+            self.layers.append(lw)
             del qkv
         self.norm = w("model.norm.weight")
         self.embed = w("model.embed_tokens.weight")
@@ -126,6 +149,15 @@ class NativeTarget:
                        attn_ws=ops.attn_fused_ws(self.n_q, self.n_kv, max_splits, dev), argmax_ws=ops.argmax_ws(dev),
                        xq=z(16 * NT, self.nqkv), head_ws=ops.attn_head_ws(self.n_q, max_splits, NT, dev),
                        post=torch.zeros(16 * NT, dtype=torch.int64, device=dev))
+        self.is_moe = any("gu_e" in lw for lw in self.layers)
+        if self.is_moe:
+            ep = (self.E + 15) // 16 * 16
+            self.moe_nsplit = 2
+            self.ws.update(xn=z(NT, 16 * self.H), xn1=z(NT, 16 * self.H), rlog=z(NT, 16, ep), wt=z(NT, 16, self.E),
+                           act_e=z(self.E, 16 * self.Ie), moe_part=z(self.moe_nsplit, 16, self.H, dt=torch.float32),
+                           active=torch.zeros(self.E, dtype=torch.int32, device=dev),
+                           elist=torch.zeros(self.E, dtype=torch.int32, device=dev),
+                           n_active=torch.zeros(1, dtype=torch.int32, device=dev))
         ws, nt = self.ws, self.H // 16
         hs = [ws["h"][16 * t:16 * t + 16] for t in range(NT)]
         # row sources, one per tile: the consuming GEMM applies the RMSNorm itself (no norm launches)
@@ -137,6 +169,10 @@ class NativeTarget:
                  for lw in self.layers],
             final=[ops.rows_normed(hs[t], ws["ss_h"][t], nt, self.norm, self.eps, ops.DYN_BS) for t in range(NT)],
             attn=[ops.rows_frag(ws["attn"][t]) for t in range(NT)], act=[ops.rows_frag(ws["act"][t]) for t in range(NT)])
+        if self.is_moe:   # MoE layers hand their successor ready-normalised rows (the residual add + norm launch after the experts)
+            self.src["xn"] = [ops.rows_frag(ws["xn"][t]) for t in range(NT)]
+            self.src["xn1"] = [ops.rows_frag(ws["xn1"][t]) for t in range(NT)]
+        self.debug_routing = None
         self._rope = None
         self._taps = {}
         torch.cuda.synchronize(dev)
@@ -185,6 +221,28 @@ class NativeTarget:
         cache.length = P
         return out
 
+    def _moe_mlp(self, i: int, lw: dict, tiles, hrow, taps, sl) -> None:
+        """Qwen3MoeSparseMoeBlock of layer i on the block rows (tf:models/qwen3_moe/modeling_qwen3_moe.py): norm, router
+        GEMM, softmax/top-k/renormalise, gate/up of every active expert in one launch, the routing-weighted down
+        projections as fp32 K-part sums, then residual add + tap + the NEXT stage's RMSNorm in one row-wise launch."""
+        ws, H, E = self.ws, self.H, self.E
+        nxt = self.layers[i + 1]["ln1"] if i + 1 < self.L else self.norm
+        for t, dt in tiles:
+            ops.norm_pack(norm_w=lw["ln2"], frag=ws["xn"][t], H=H, eps=self.eps, resid_in=hrow[t], dyn=dt,
+                          dyn_word=ops.DYN_BS)
+            ops.gemm_resid(lw["router"], self.src["xn"][t], ws["rlog"].shape[2], H, ws["rlog"][t], add_residual=False, dyn=dt)
+            ops.moe_route(ws["rlog"][t], E, self.top_k, self.norm_topk, ws["wt"][t], ws["active"], ws["elist"],
+                          ws["n_active"], dyn=dt, dyn_word=ops.DYN_BS)
+            if self.debug_routing is not None and t == 0:    # tests: the routing weights of every MoE layer
+                self.debug_routing.append((i, ws["wt"][0].clone()))
+            ops.gemm_silu_mul_experts(lw["gu_e"], self.src["xn"][t], E, self.Ie, H, ws["act_e"], ws["active"], dyn=dt)
+            ops.moe_down(lw["down_e"], ws["act_e"], ws["wt"][t], ws["elist"], ws["n_active"], E, H, self.Ie,
+                         self.moe_nsplit, ws["moe_part"])
+            tap = taps[16 * t:16 * t + 16, sl[0] * H:(sl[0] + 1) * H] if sl else None
+            ops.norm_pack(norm_w=nxt, frag=ws["xn1"][t], H=H, eps=self.eps, part=ws["moe_part"], nsplit=self.moe_nsplit,
+                          part_split=16 * H, ldp=H, resid_in=hrow[t], h_out=hrow[t], h_out2=tap,
+                          ld2=taps.stride(0) if tap is not None else 0, dyn=dt, dyn_word=ops.DYN_BS)
+
     # ---- the verify forward on the kernels
     @torch.inference_mode()
     def verify(self, block_ids: torch.Tensor, start: int, cache: TargetKVCache, *, tap_layers: Sequence[int] = (),
@@ -229,20 +287,21 @@ class NativeTarget:
         hrow = [ws["h"][16 * t:16 * t + 16] for t in range(2)]
         for t, dt in tiles:
             ops.embed_rows(self.embed, block_ids[16 * t:], hrow[t], H, ws["ss_emb"][16 * t:], dt, ops.DYN_BS)
+        prev_moe = False   # an MoE layer leaves its successor's input already normalised (frag16 in ws["xn1"])
         for i, lw in enumerate(Ls):
+            x1 = src["xn1"] if prev_moe else src["ln1"][i]
             if self.attn_impl == "head":
                 # q/k/v as finished bf16 Linear outputs (no K split: 192 workgroups x 2 column tiles), then
                 # one launch: q/k-norm + RoPE + append + causal attention + split merge
                 for t, dt in tiles:
-                    ops.gemm_resid(lw["qkv"], src["ln1"][i][t], self.nqkv, H, ws["xq"][16 * t:], add_residual=False,
-                                   dyn=dt)
+                    ops.gemm_resid(lw["qkv"], x1[t], self.nqkv, H, ws["xq"][16 * t:], add_residual=False, dyn=dt)
                 ops.attn_head(xq=ws["xq"], q_col=0, k_col=self.q_dim, v_col=self.q_dim + self.kv_dim, n_q=self.n_q,
                               n_kv=self.n_kv, q_norm_w=lw["q_norm"], k_norm_w=lw["k_norm"], eps=self.eps, cos_tab=cos,
                               sin_tab=sin, kcache=cache.k[i], vcache=cache.v[i], scale=128 ** -0.5, causal=True,
                               S=start, tau=0, bs=bs, pos0=start, ws=ws["head_ws"], max_splits=self.max_splits,
                               out_frag=ws["attn"], q_tiles=len(tiles), out_tile_stride=ws["attn"].stride(0))
             else:
-                ops.gemm_f32(lw["qkv"], src["ln1"][i][0], None, 1, self.nqkv, H, self.ks_qkv, ws["part"], dyn)
+                ops.gemm_f32(lw["qkv"], x1[0], None, 1, self.nqkv, H, self.ks_qkv, ws["part"], dyn)
                 ops.attn_fused(qkv=ws["part"], nsplit=self.ks_qkv, split_stride=16 * self.nqkv, ld=self.nqkv, q_col=0,
                                k_col=self.q_dim, v_col=self.q_dim + self.kv_dim, ctx_row0=0, blk_row0=0, n_q=self.n_q,
                                n_kv=self.n_kv, q_norm_w=lw["q_norm"], k_norm_w=lw["k_norm"], eps=self.eps,
@@ -252,23 +311,28 @@ class NativeTarget:
             for t, dt in tiles:
                 ops.gemm_resid(lw["o"], src["attn"][t], H, self.q_dim, hrow[t], add_residual=True,
                                ss_out=ws["ss_h"][t], dyn=dt)
-            for t, dt in tiles:
-                ops.gemm_silu_mul(lw["gu"], src["ln2"][i][t], self.I, H, ws["act"][t], dt)
             # every slot j with tap_layers[j] == i: build_target_layer_ids repeats layers for shallow
             # targets and the reference concatenates the same state twice (model/utils.py:16-25)
             sl = [j for j, l in enumerate(tap_layers) if l == i]
-            for t, dt in tiles:
-                tap = taps[16 * t:16 * t + 16, sl[0] * H:(sl[0] + 1) * H] if sl else None
-                ops.gemm_resid(lw["down"], src["act"][t], H, self.I, hrow[t], add_residual=True, ss_out=ws["ss_h"][t],
-                               tap=tap, dyn=dt)
+            prev_moe = "gu_e" in lw
+            if prev_moe:
+                self._moe_mlp(i, lw, tiles, hrow, taps, sl)
+            else:
+                for t, dt in tiles:
+                    ops.gemm_silu_mul(lw["gu"], src["ln2"][i][t], self.I, H, ws["act"][t], dt)
+                for t, dt in tiles:
+                    tap = taps[16 * t:16 * t + 16, sl[0] * H:(sl[0] + 1) * H] if sl else None
+                    ops.gemm_resid(lw["down"], src["act"][t], H, self.I, hrow[t], add_residual=True,
+                                   ss_out=ws["ss_h"][t], tap=tap, dyn=dt)
             for j in sl[1:]:
                 taps[:, j * H:(j + 1) * H].copy_(taps[:, sl[0] * H:(sl[0] + 1) * H])
         post = ws["post"]
         logits = logits_out
         if temperature >= 1e-5:
             logits = torch.empty(16 * len(tiles), self.V, dtype=BF16, device=self._dev)
+        fin = src["xn1"] if prev_moe else src["final"]   # after an MoE layer the rows are final-normed already
         for t, dt in tiles:
-            ops.gemm_argmax(self.lm_wp, src["final"][t], self.V, H, 0, min(16, bs - 16 * t), ws["argmax_ws"], post, 16 * t,
+            ops.gemm_argmax(self.lm_wp, fin[t], self.V, H, 0, min(16, bs - 16 * t), ws["argmax_ws"], post, 16 * t,
                             dyn=dt, logits=None if logits is None else logits[16 * t:16 * t + 16])
         if temperature < 1e-5:
             posterior = post[:bs].unsqueeze(0)

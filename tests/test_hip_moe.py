@@ -1,0 +1,202 @@
+"""Sparse-MoE target on the native verify (BASELINE configs[4], Qwen3-Coder-30B-A3B class): router, grouped expert
+GEMMs, and the whole verify against the HF Qwen3MoeForCausalLM forward."""
+import pytest
+import torch
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+BF16 = torch.bfloat16
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+def _moe_hf(layers=4, E=16, top_k=4, Ie=256, mlp_only=(), dtype=BF16, seed=41, norm_topk=True):
+    tf = pytest.importorskip("transformers")
+    cfg = tf.Qwen3MoeConfig(vocab_size=2048, hidden_size=512, intermediate_size=1024, moe_intermediate_size=Ie,
+                            num_hidden_layers=layers, num_attention_heads=4, num_key_value_heads=2, head_dim=128,
+                            num_experts=E, num_experts_per_tok=top_k, decoder_sparse_step=1, norm_topk_prob=norm_topk,
+                            max_position_embeddings=4096, rms_norm_eps=1e-6, tie_word_embeddings=False,
+                            rope_parameters={"rope_type": "default", "rope_theta": 1e6}, mlp_only_layers=list(mlp_only))
+    cfg._attn_implementation = "sdpa"
+    torch.manual_seed(seed)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        with torch.device(dev()):
+            m = tf.Qwen3MoeForCausalLM(cfg)
+    finally:
+        torch.set_default_dtype(prev)
+    with torch.no_grad():   # the default init leaves the router nearly flat: give the routing something to decide
+        for layer in m.model.layers:
+            if hasattr(layer.mlp, "gate"):
+                layer.mlp.gate.weight.mul_(8.0)
+    return m.eval()
+
+
+@pytest.mark.parametrize("E,top_k,norm", [(16, 4, True), (128, 8, True), (24, 2, False), (200, 8, True)])
+def test_moe_route_matches_torch(E, top_k, norm):
+    """dfl_moe_route vs Qwen3MoeTopKRouter.forward's arithmetic (fp32 softmax of the bf16 logits, top-k, renormalise,
+    cast): the dense weight matrix, the active flags and the ascending list; rows beyond the block route nowhere."""
+    from dflash_amd import ops
+    g = torch.Generator().manual_seed(E + top_k)
+    ep = (E + 15) // 16 * 16
+    logits = torch.zeros(16, ep, dtype=BF16)
+    logits[:, :E] = (torch.randn(16, E, generator=g) * 3).to(BF16)
+    rows = 11
+    dyn = torch.zeros(8, dtype=torch.int32, device=dev())
+    ops.set_dyn(dyn, 0, 0, rows, 0)
+    wt = torch.full((16, E), 7.0, dtype=BF16, device=dev())
+    active = torch.full((E,), 9, dtype=torch.int32, device=dev())
+    lst = torch.zeros(E, dtype=torch.int32, device=dev())
+    n = torch.zeros(1, dtype=torch.int32, device=dev())
+    ops.moe_route(logits.to(dev()), E, top_k, norm, wt, active, lst, n, dyn=dyn, dyn_word=ops.DYN_BS)
+    p = torch.softmax(logits[:rows, :E].float(), dim=-1)
+    v, i = torch.topk(p, top_k, dim=-1)
+    if norm:
+        v = v / v.sum(dim=-1, keepdim=True)
+    ref = torch.zeros(16, E, dtype=torch.float32)
+    ok_rows = []
+    for m in range(rows):      # rows whose k-th and (k+1)-th probabilities differ: the selection is unambiguous
+        srt = p[m].sort(descending=True).values
+        if len(set(srt[:top_k + 1].tolist())) == top_k + 1:
+            ok_rows.append(m)
+        ref[m, i[m]] = v[m].to(BF16).float()
+    got = wt.float().cpu()
+    assert len(ok_rows) >= rows // 2          # (bf16 logits tie: with 200 experts several rows have equal top-9 values)
+    assert torch.equal(got[rows:], torch.zeros(16 - rows, E))
+    for m in ok_rows:
+        assert (got[m] != 0).sum() == top_k
+        assert torch.equal(got[m] != 0, ref[m] != 0), m
+        assert torch.allclose(got[m], ref[m], rtol=2 ** -7, atol=1e-4)
+    act_ref = (got != 0).any(dim=0)
+    assert torch.equal(active.cpu() != 0, act_ref)
+    k = int(n)
+    assert k == int(act_ref.sum()) and lst[:k].cpu().tolist() == act_ref.nonzero()[:, 0].tolist()
+
+
+def test_grouped_expert_gemms_match_torch():
+    """dfl_gemm_silu_mul_experts + dfl_moe_down against the HF experts loop in fp32 (Qwen3MoeExperts.forward): only the
+    active experts' outputs are computed, the routing-weighted sum over experts comes out as K-part sums."""
+    from dflash_amd import ops
+    g = torch.Generator().manual_seed(5)
+    E, I, Hd, rows = 16, 256, 512, 13
+    gu = (torch.randn(E, 2 * I, Hd, generator=g) * 0.05).to(BF16).to(dev())
+    dn = (torch.randn(E, Hd, I, generator=g) * 0.05).to(BF16).to(dev())
+    x = torch.randn(16, Hd, generator=g).to(BF16).to(dev())
+    x[rows:] = 0
+    wt = torch.zeros(16, E, dtype=BF16, device=dev())
+    for m in range(rows):
+        sel = torch.randperm(E, generator=g)[:3]
+        wt[m, sel] = torch.rand(3, generator=g).to(BF16).to(dev())
+    active = (wt != 0).any(dim=0).to(torch.int32)
+    lst = torch.zeros(E, dtype=torch.int32, device=dev())
+    k = int(active.sum())
+    lst[:k] = active.nonzero()[:, 0].to(torch.int32)
+    n = torch.tensor([k], dtype=torch.int32, device=dev())
+    assert 0 < k < E
+    gu_p = torch.stack([ops.pack_weight_gateup(gu[e, :I].contiguous(), gu[e, I:].contiguous()) for e in range(E)])
+    dn_p = torch.stack([ops.pack_weight(dn[e].contiguous()) for e in range(E)])
+    xf = torch.empty(16 * Hd, dtype=BF16, device=dev())
+    ops.pack_rows(x, 16, xf)
+    act = torch.full((E, 16 * I), float("nan"), dtype=BF16, device=dev())
+    ops.gemm_silu_mul_experts(gu_p, ops.rows_frag(xf), E, I, Hd, act, active)
+    out = torch.zeros(2, 16, Hd, dtype=torch.float32, device=dev())
+    ops.moe_down(dn_p, act, wt, lst, n, E, Hd, I, 2, out)
+    got = out.sum(0)
+    ref = torch.zeros(16, Hd, device=dev())
+    for e in range(E):
+        if not active[e]:
+            assert torch.isnan(act[e].float()).all()        # inactive experts were not touched
+            continue
+        gate, up = (x.float() @ gu[e].float().T).to(BF16).chunk(2, dim=-1)
+        a = (torch.nn.functional.silu(gate.float()).to(BF16).float() * up.float()).to(BF16)
+        ref += wt[:, e].float()[:, None] * (a.float() @ dn[e].float().T)
+    assert (got - ref).abs().max() <= 2e-2 * ref.abs().max()
+    assert (got - ref).abs().mean() <= 3e-3 * ref.abs().max()
+
+
+@pytest.mark.parametrize("mlp_only", [(), (1,)])
+def test_native_moe_verify_matches_hf_forward(mlp_only):
+    """A Qwen3MoeForCausalLM (16 experts, top-4; optionally a dense layer in between) through NativeTarget.verify vs
+    its own forward: router decisions equal on (almost) every row, logits / taps / K/V of the rows whose routing
+    agrees within the bf16 tolerance, posterior ids on margin-screened rows."""
+    from transformers import DynamicCache
+    from dflash_amd import NativeTarget
+    hf = _moe_hf(mlp_only=mlp_only)
+    nt = NativeTarget(hf)
+    assert nt.is_moe and ("gu" in nt.layers[1]) == bool(mlp_only)
+    g = torch.Generator().manual_seed(7)
+    P, bs = 50, 16
+    prompt = torch.randint(0, 2000, (1, P), generator=g).to(dev())
+    block = torch.randint(0, 2000, (1, bs), generator=g).to(dev())
+    cache = nt.new_cache(128)
+    nt.prefill(prompt, cache)
+    logits = torch.zeros(32, 2048, dtype=BF16, device=dev())
+    nt.debug_routing = []
+    post, th = nt.verify(block[0], P, cache, tap_layers=[0, 2], logits_out=logits)
+    routing = nt.debug_routing
+    nt.debug_routing = None
+    rc = DynamicCache()
+    with torch.inference_mode():
+        hf(prompt, past_key_values=rc, use_cache=True)
+        ref = hf(block, position_ids=torch.arange(P, P + bs, device=dev())[None], past_key_values=rc, use_cache=True,
+                 output_hidden_states=True, output_router_logits=True)
+    moe_layers = [i for i in range(4) if i not in mlp_only]
+    assert len(routing) == len(moe_layers) == len(ref.router_logits)
+    same = torch.ones(bs, dtype=torch.bool)
+    for (li, wt), rl in zip(routing, ref.router_logits):
+        p = torch.softmax(rl.float(), dim=-1)
+        idx = torch.topk(p, 4, dim=-1).indices.cpu()
+        want = torch.zeros(bs, 16, dtype=torch.bool)
+        want[torch.arange(bs)[:, None], idx] = True
+        same &= ((wt[:bs].float().cpu() != 0) == want).all(dim=-1)
+    assert int(same.sum()) >= bs - 3, same          # a near-tie at the k-th place may fall either way in bf16
+    rows = same.nonzero()[:, 0].to(dev())
+    H.assert_close("MoE verify logits", logits[:bs][rows], ref.logits[0][rows])
+    assert torch.equal(post[0], torch.argmax(logits[:bs], dim=-1))
+    H.assert_ids_match_where_safe("MoE verify ids", post[0][rows], ref.logits[0][rows])
+    for j, l in enumerate((0, 2)):
+        H.assert_close(f"MoE verify tap {l}", th[:bs, j * 512:(j + 1) * 512][rows], ref.hidden_states[l + 1][0][rows])
+    for li in (0, 3):
+        H.assert_close(f"MoE verify K layer {li}", cache.k[li][:, :P + bs][:, torch.cat([torch.arange(P, device=dev()), P + rows])],
+                       rc.layers[li].keys[0][:, torch.cat([torch.arange(P, device=dev()), P + rows])], max_rel=H.KV_MAX_REL)
+
+
+def test_native_moe_target_end_to_end_lossless_walk():
+    """dflash_generate / dflash_generate_policy on the NATIVE MoE verify with a large-margin greedy rule: committed ids
+    are the target's closed-form greedy walk at block 16 and over a {8, 12, 16} schedule, scripted acceptance."""
+    from dflash_amd import (DFlashDraftModel, EWMAPerformanceScheduler, NativeTarget, dflash_generate,
+                            dflash_generate_policy)
+    from dflash_amd.synthetic import greedy_walk, impose_greedy_walk
+    cfg = H.tiny_cfg(num_target_layers=4, target_layer_ids=[0, 2])
+    m = DFlashDraftModel(cfg, device=dev())
+    m.load_state_dict(H.draft_weights(cfg, dtype=BF16))
+    hf = _moe_hf()
+    perm = impose_greedy_walk(hf, seed=5)
+    nt = NativeTarget(hf)
+    prompt = torch.randint(0, 2000, (1, 30), generator=torch.Generator().manual_seed(4)).to(dev())
+    n_new = 60
+    G = greedy_walk(perm, prompt, n_new + 40).to(dev())
+    plan = H.make_plan(64, 16, 17)
+
+    def hook(blk, start, call):
+        k = min(plan[call], blk.shape[1] - 1)
+        blk[0, 1:k + 1] = G[start + 1:start + k + 1]
+        if k + 1 < blk.shape[1]:
+            w = G[start + k + 1]
+            blk[0, k + 1] = torch.where(blk[0, k + 1] == w, (w + 1) % 2000, blk[0, k + 1])
+
+    r = dflash_generate(m, nt, prompt, cfg.mask_token_id, n_new, 16, None, 0.0, draft_token_hook=hook)
+    assert r.output_ids[0].tolist() == G[:30 + n_new].tolist()
+    assert max(r.acceptance_lengths) == 16
+    sched = EWMAPerformanceScheduler(candidates=[8, 12, 16], scheduler_mode="ewma", warmup_cycles=3, ewma_alpha=0.25,
+                                     switch_margin=0.03, required_streak=2, cooldown_cycles=2, probe_interval=5,
+                                     low_accept_threshold=0.2, low_accept_streak=3, adl_rho=0.3, adl_delta=1.0,
+                                     adl_k_min=8, adl_k_max=16, adl_neighborhood=4)
+    rp = dflash_generate_policy(model=m, target=nt, input_ids=prompt, mask_token_id=cfg.mask_token_id,
+                                max_new_tokens=n_new, stop_token_ids=None, temperature=0.0, scheduler=sched,
+                                draft_token_hook=hook)
+    assert rp.output_ids[0].tolist() == G[:30 + n_new].tolist()
