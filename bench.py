@@ -105,9 +105,11 @@ def gpu_leg(args, rank, world, dev):
     if not args.hf_verify:
         from dflash_amd import NativeTarget
         target = NativeTarget(target, attn_impl=args.attn_impl)   # verify on the kernels, prefill through HF
+        target.fuse_oproj = args.fuse_oproj
     cfg = DFlashConfig(**{**QWEN3_8B_DRAFT, "num_target_layers": args.target_layers})
     draft = DFlashDraftModel(cfg, device=dev)
     draft.attn_impl = args.attn_impl
+    draft.fuse_oproj = args.fuse_oproj
     # seeded init directly on the GPU (CPU generation of 1e9 normals costs a minute)
     g = torch.Generator(device=dev).manual_seed(0)
     sd = {k: (torch.randn(s, generator=g, device=dev, dtype=torch.float32) * 0.02).to(torch.bfloat16)
@@ -443,6 +445,8 @@ def main():
     ap.add_argument("--hf-verify", action="store_true",
                     help="verify through the HF/PyTorch target forward (round-1 configuration) instead of "
                          "dflash_amd.NativeTarget")
+    ap.add_argument("--fuse-oproj", action="store_true",
+                    help="A/B: attention stage and o_proj as ONE launch (dfl_attn_head_oproj; measured slower, off by default)")
     ap.add_argument("--attn-impl", choices=["head", "fused"], default="head",
                     help="attention stage of the native verify: head = dfl_attn_head (round 2), fused = dfl_attn_fused (round 1)")
     ap.add_argument("--selftest-cpu", action="store_true",

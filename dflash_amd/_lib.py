@@ -56,6 +56,8 @@ SIGNATURES = {
     "dfl_attn_head_ws_bytes": (_i64, [_i, _i, _i]),
     "dfl_attn_head": (_i, [_p, _i64, _i, _i, _i, _p, _i64, _i, _i, _i, _i, _p, _p, _f, _p, _p, _i, _p, _p, _i, _f, _i,
                            _p, _i, _i, _i, _i, _i, _p, _i, _p, _i64, _p]),
+    "dfl_attn_head_oproj": (_i, [_p, _i64, _i, _i, _i, _p, _i64, _i, _i, _i, _i, _p, _p, _f, _p, _p, _i, _p, _p, _i, _f, _i,
+                                 _p, _i, _i, _i, _i, _p, _i, _p, _p, _i, _p, _i64, _p, _p, _p]),
     "dfl_attn_head_cand": (_i, [_p, _i64, _i, _i, _i, _i, _i64, _i, _i, _p, _p, _f, _p, _p, _i, _p, _p, _i, _f, _i, _i,
                                 _p, _i, _p, _i64, _p, _p, _i64, _i, _p]),
     "dfl_attn_head_batch": (_i, [_p, _i64, _i, _i, _i, _i, _i64, _i, _i, _p, _p, _f, _p, _p, _i, _p, _p, _i, _i64, _f, _i,

@@ -28,7 +28,7 @@
 //   * lengths may come as immediates (host-driven loop) instead of a dependent scalar load.
 // MFMA: S^T = K Q^T and O^T += V^T P^T on v_mfma_f32_16x16x32_bf16 as in attn_block.hip (same
 // fragment layouts, same base-2 online softmax in fp32, P rounded to bf16 for the PV product).
-#include "dfl_common.h"
+#include "gemm_rows.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -189,41 +189,53 @@ __device__ unsigned long long g_hstamps[2][8];
     if (tid == 0 && kvh == 0 && hh == 0 && (split == 0 || is_new))                                 \
       g_hstamps[is_new ? 1 : 0][i] = __builtin_amdgcn_s_memrealtime();                             \
   } while (0)
+// ... and of the first and the last o_proj workgroup of k_attn_oproj [0], [1] (scripts/dbg_attn_oproj_stamps.py)
+__device__ unsigned long long g_ostamps[2][8];
+// [split]: latest ticket-time of any attention workgroup of that key split; [15]: latest head-done signal
+__device__ unsigned long long g_amax[16];
+#define OSTAMP(i)                                                                                  \
+  do {                                                                                             \
+    if (tid == 0 && (t == 0 || t == p.ntiles - 1)) g_ostamps[t ? 1 : 0][i] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
 #else
 #define HSTAMP(i)
+#define OSTAMP(i)
 #endif
 
-template <int QT>
+template <int QT, int NW>
 struct HeadLds {
-  static constexpr int kVPriv = 8 * 8192;            // wave-private V tiles (old splits) | new K, new V (new split)
+  static_assert(NW * 4 >= QT * 16 && NW * 8192 >= 32768, "q rows: 4 per wave; new K / V: two 32-row tiles each");
+  static constexpr int kVPriv = NW * 8192;           // wave-private V tiles (old splits) | new K, new V (new split)
   static constexpr int kQ = kVPriv;                  // q rows, swizzled like K: QT * 4 KB
   static constexpr int kLoop = kVPriv + QT * 4096;
-  // after the loop: 8 waves x QT x [16][kRow] fp32, rows padded 128 -> 132 floats: the 16 query rows of a wave's
+  // after the loop: NW waves x QT x [16][kRow] fp32, rows padded 128 -> 132 floats: the 16 query rows of a wave's
   // ds_write_b128 (and of the merge's ds_read_b128) then fall on different banks (unpadded: 8-way conflicts,
   // 2.3 us of the stage)
   static constexpr int kRow = 132;
   static constexpr int kMergeO = 0;
-  static constexpr int kMergeML = 8 * QT * 16 * kRow * 4;  // 8 waves x QT x [16][2] fp32
-  static constexpr int kMerge = kMergeML + 8 * QT * 128;
+  static constexpr int kMergeML = NW * QT * 16 * kRow * 4;  // NW waves x QT x [16][2] fp32
+  static constexpr int kMerge = kMergeML + NW * QT * 128;
   static constexpr int kRaw = kLoop > kMerge ? kLoop : kMerge;
-  // > 80 KB: one workgroup per CU, the geometry the sc1 hand-off is measured for
-  static constexpr int kBytes = kRaw > 84 * 1024 ? kRaw : 84 * 1024;
+  // 8 waves: > 80 KB, one workgroup per CU, the geometry the sc1 hand-off is measured for
+  static constexpr int kBytes = NW < 8 ? kRaw : (kRaw > 84 * 1024 ? kRaw : 84 * 1024);
 };
 
-template <int QT>
-__global__ __launch_bounds__(512) void k_attn_head(HeadAttnArgs a) {
-  using L = HeadLds<QT>;
-  __shared__ __attribute__((aligned(16))) char lds[L::kBytes];
-  __shared__ int s_last;
+// The stage as a device function of an NW-wave workgroup: k_attn_head runs it alone on 8 waves; k_attn_oproj runs it on 4,
+// beside the o_proj workgroups that wait for it (SIGNAL: the workgroup that writes a head's final output stores it
+// write-through and then counts the head on *done_ctr).  (kvh, by, cand) = blockIdx.x / .y / .z of k_attn_head:
+// cand = candidate of a multi-candidate verify / request of a ragged batch (0 otherwise).
+template <int QT, int NW, bool SIGNAL>
+__device__ __forceinline__ void attn_head_body(const HeadAttnArgs &a, char *lds, int *s_last_p, const int kvh, const int by,
+                                               const int cand, int *done_ctr) {
+  using L = HeadLds<QT, NW>;
+  int &s_last = *s_last_p;
 
   const int tid = threadIdx.x;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
-  const int kvh = blockIdx.x;
-  const int hh = (int)blockIdx.y % a.G, split = (int)blockIdx.y / a.G;
+  const int hh = by % a.G, split = by / a.G;
   const int head = kvh * a.G + hh;
   const int ns = a.ns_old + 1;
   const bool is_new = split == a.ns_old;
-  const int cand = blockIdx.z;  // candidate of a multi-candidate verify / request of a ragged batch (0 otherwise)
   int S = a.S, tau = a.tau, bs = a.bs, pos0 = a.pos0;
   if (a.dyn) {
     const int32_t *dp = a.dyn + cand * a.dyn_cand_stride;
@@ -250,7 +262,7 @@ __global__ __launch_bounds__(512) void k_attn_head(HeadAttnArgs a) {
   const bf16_t *vbase = vc + (int64_t)kvh * a.cache_rows * 128;
 
 
-  // ---- old-key tiles of this split; wave w walks t0 + w, t0 + w + 8, ...
+  // ---- old-key tiles of this split; wave w walks t0 + w, t0 + w + NW, ...
   int t0 = 0, t1 = 0;
   if (!is_new && a.ns_old > 0) {
     const int nt = (S + 31) >> 5;
@@ -323,7 +335,7 @@ __global__ __launch_bounds__(512) void k_attn_head(HeadAttnArgs a) {
       bf16x8 ov[NP];
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
-        const int it = (p * 8 + w) * 4 + g;  // 32 items per pass
+        const int it = (p * NW + w) * 4 + g;  // 4 NW items per pass
         isv[p] = it >= n_new;
         rel[p] = isv[p] ? it - n_new : it;
         const bool ok = it < 2 * n_new;
@@ -351,11 +363,11 @@ __global__ __launch_bounds__(512) void k_attn_head(HeadAttnArgs a) {
             *reinterpret_cast<bf16x8 *>((isv[p] ? v_new : k_new) + ((int64_t)kvh * new_rows_cap + crow) * 128 + qi * 8) = ov[p];
         }
     };
-    if (2 * n_new <= 32)
+    if (2 * n_new <= NW * 4)
       sweep(std::integral_constant<int, 1>{});
-    else if (2 * n_new <= 64)
+    else if (2 * n_new <= NW * 8)
       sweep(std::integral_constant<int, 2>{});
-    else
+    else  // (the host function of a 4-wave launch admits tau + bs <= 32)
       sweep(std::integral_constant<int, 4>{});
   }
   HSTAMP(1);
@@ -461,18 +473,18 @@ __global__ __launch_bounds__(512) void k_attn_head(HeadAttnArgs a) {
       }
     };
     // the wave's own LDS tile: its ds_write -> ds_read order is program order (lgkmcnt), no barrier
-    for (; tcur < t1; tcur += 16) {
-      if (tcur + 8 < t1) fetch(kB, vB, tcur + 8);
+    for (; tcur < t1; tcur += 2 * NW) {
+      if (tcur + NW < t1) fetch(kB, vB, tcur + NW);
       put_v(vA);
       compute(kA, my_v, tcur * 32, S, 32, false);
-      if (tcur + 8 >= t1) break;
-      if (tcur + 16 < t1) fetch(kA, vA, tcur + 16);
+      if (tcur + NW >= t1) break;
+      if (tcur + 2 * NW < t1) fetch(kA, vA, tcur + 2 * NW);
       put_v(vB);
-      compute(kB, my_v, (tcur + 8) * 32, S, 32, false);
+      compute(kB, my_v, (tcur + NW) * 32, S, 32, false);
     }
   }
 
-  // ---- the 8 waves meet in LDS
+  // ---- the NW waves meet in LDS
   HSTAMP(2);
   __syncthreads();
   HSTAMP(3);
@@ -492,10 +504,7 @@ __global__ __launch_bounds__(512) void k_attn_head(HeadAttnArgs a) {
     }
   }
   __syncthreads();
-  if (tid >= QT * 256) {  // QT = 1: the upper 4 waves have no item (they still join the barriers below)
-    if (ns == 1) return;
-  }
-  const bool has_item = tid < QT * 256;
+  const bool has_item = tid < QT * 256;  // QT = 1 on 8 waves: the upper 4 have no item (they still join the barriers)
   const int qt = tid >> 8, q = (tid >> 4) & 15, dg = tid & 15;
   float M = -INFINITY, Lsum = 0.f, acc[8];
 #pragma unroll
@@ -503,16 +512,16 @@ __global__ __launch_bounds__(512) void k_attn_head(HeadAttnArgs a) {
   if (has_item) {
     const float *mo = reinterpret_cast<const float *>(lds + L::kMergeO);
     const float *mml = reinterpret_cast<const float *>(lds + L::kMergeML);
-    float ms[8], ls[8];
+    float ms[NW], ls[NW];
 #pragma unroll
-    for (int ww = 0; ww < 8; ++ww) {
+    for (int ww = 0; ww < NW; ++ww) {
       ms[ww] = mml[((ww * QT + qt) * 16 + q) * 2];
       ls[ww] = mml[((ww * QT + qt) * 16 + q) * 2 + 1];
       M = fmaxf(M, ms[ww]);
     }
     const float mref = M == -INFINITY ? 0.f : M;
 #pragma unroll
-    for (int ww = 0; ww < 8; ++ww) {  // fixed wave order: reproducible sums
+    for (int ww = 0; ww < NW; ++ww) {  // fixed wave order: reproducible sums
       const float wgt = __builtin_amdgcn_exp2f(ms[ww] - mref);  // exp2(-inf) = 0: a wave without tiles
       const float *op = mo + ((ww * QT + qt) * 16 + q) * L::kRow + dg * 8;
       const f32x4 a0 = *reinterpret_cast<const f32x4 *>(op), a1 = *reinterpret_cast<const f32x4 *>(op + 4);
@@ -529,11 +538,33 @@ __global__ __launch_bounds__(512) void k_attn_head(HeadAttnArgs a) {
     bf16x8 r;
 #pragma unroll
     for (int j = 0; j < 8; ++j) r[j] = f2bf(v[j] * inv);
-    out_frag[qt * a.out_tile_stride + (head * 16 + dg) * 16 + q] = r;
+    if (SIGNAL && q >= bs) r = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};  // the GEMM behind it takes rows >= bs as zero
+    bf16x8 *dst = &out_frag[qt * a.out_tile_stride + (head * 16 + dg) * 16 + q];
+    if (SIGNAL) {  // read by other workgroups of THIS launch: write-through
+      const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(dst, 0, 16, 0x00020000);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r), rd, 0, 0, 16);
+    } else {
+      *dst = r;
+    }
+  };
+  // SIGNAL: every storing wave drains, the workgroup meets, one lane counts the head as done (hand-off row 1 of the
+  // table in MI355X_MICROARCH.md: sc1 stores, drain, barrier, agent-scope add; consumers poll, barrier, sc1 loads)
+  auto signal = [&]() {
+    if (SIGNAL) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      // one wave instruction, 32 lanes: +1 on each of the 32 replicas of the counter (a line of its own each), so that a
+      // replica has 8 pollers, not 256
+      if (tid < 32) __hip_atomic_fetch_add(done_ctr + tid * 32, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef DFL_ATTN_STAMPS
+      if (tid == 0) atomicMax(&g_amax[15], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
+    }
   };
   HSTAMP(4);
   if (ns == 1) {
     if (has_item) emit(Lsum, acc);
+    signal();
     return;
   }
 
@@ -566,10 +597,13 @@ __global__ __launch_bounds__(512) void k_attn_head(HeadAttnArgs a) {
   }
   __syncthreads();
   HSTAMP(6);
-  if (!s_last || !has_item) return;
+#ifdef DFL_ATTN_STAMPS
+  if (tid == 0) atomicMax(&g_amax[split < 15 ? split : 14], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
+  if (!s_last) return;
 
   // every load of the handed-off bytes is an sc1 load (L2-served): no acquire needed
-  {
+  if (has_item) {
     float Mg = -INFINITY, Lg = 0.f, ag[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) ag[j] = 0.f;
@@ -609,8 +643,145 @@ __global__ __launch_bounds__(512) void k_attn_head(HeadAttnArgs a) {
     }
     emit(Lg, ag);
   }
+  signal();
+#ifdef DFL_ATTN_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
   HSTAMP(7);
+}
+
+template <int QT>
+__global__ __launch_bounds__(512) void k_attn_head(HeadAttnArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds[HeadLds<QT, 8>::kBytes];
+  __shared__ int s_last;
+  attn_head_body<QT, 8, false>(a, lds, &s_last, blockIdx.x, blockIdx.y, blockIdx.z, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Attention stage + o_proj in ONE launch (round 2; VERDICT r1 item 4: a stage pair kept inside a launch where the
+// hand-off buys more than the boundary it replaces).  The attention stage leaves HBM idle for ~10 us per layer, and
+// o_proj's weights (Qwen3-8B: 33.5 MB = 131 KB per CU) fit the chip's register files.  So the launch carries, behind
+// the attention workgroups, one workgroup per 16-column output tile of o_proj that requests its whole weight slice
+// (32 k-steps per wave = 128 VGPRs) the moment it starts — the weights stream from HBM WHILE the attention runs —
+// then waits for the heads' final outputs, loads them (sc1), and is 32 MFMAs per wave, a 4-wave LDS reduction and the
+// residual epilogue away from done.
+// MEASURED (profiles/r2_attn_oproj_stamps.txt): 23.2 us per launch against 10.5 + 9.8 us for the two
+// launches it replaces, so the callers keep two launches (fuse_oproj = False) and this stays an opt-in, tested variant.
+// The weights do land early (7 us) and every workgroup is resident, but each cross-XCD hand-off costs ~2 us at either
+// end (write-through drain, then loads served from beyond L2): ticket 11.5 -> heads merged 16.5 -> seen 17.2 ->
+// 128 KB of activations per o_proj workgroup loaded 21.5 -> done 22.5, and the weight stream slows the attention
+// itself by 3 us.  The boundary it removes is priced at 1.8 us.
+//   * every workgroup has 4 waves with the 256-VGPR budget (__launch_bounds__(256, 2)): a CU holds two, whichever
+//     kind; with <= 256 attention workgroups + H/16 = 256 o_proj workgroups the whole grid is resident at once;
+//   * no attention workgroup ever waits; an o_proj workgroup waits only for attention workgroups, which have LOWER
+//     linear ids (dispatched first), so progress never depends on co-residency; the wait is BOUNDED all the same
+//     (2 ms, then *fail = 1 and the workgroup leaves: wrong numbers and a raised error, never a hang);
+//   * hand-off: the workgroup that merges a head stores its frag16 output write-through, drains, meets, and adds 1 to
+//     each of 32 replicas of `done`; one lane per o_proj workgroup polls ITS replica (relaxed agent-scope load +
+//     s_sleep), the workgroup barrier spreads the news, an agent-scope acquire fence precedes the activation loads;
+//   * the last o_proj workgroup past its wait re-arms both counters: the launch is capturable and re-launchable as is.
+struct AttnOArgs {
+  HeadAttnArgs at;
+  int n_attn;         // attention workgroups = n_kv * G * (ns_old + 1); workgroup b < n_attn: kv head b % n_kv, y = b / n_kv
+  const bf16x8 *wo;   // packed o_proj weight [ntiles][KS][64]
+  int KS, ntiles;     // q_dim / 32 (<= 128), H / 16
+  bf16_t *h_io;       // residual stream [16][ldh]: h <- bf16(h + bf16(attn . Wo^T))
+  int64_t ldh;
+  float *ss_out;      // [ntiles][16] partial sums of squares of the new rows (next GEMM's RMSNorm)
+  int *done;          // 32 replicas of the heads-done counter, 32 ints (one 128-B line) apart
+  int *o_done, *fail;
+  int done_target;    // = n_q: heads whose output must be complete
+};
+
+__global__ __launch_bounds__(256, 2) void k_attn_oproj(AttnOArgs p) {
+  __shared__ __attribute__((aligned(16))) char lds[HeadLds<1, 4>::kBytes];
+  __shared__ int s_last;
+  const int b = blockIdx.x;
+  if (b < p.n_attn) {
+    attn_head_body<1, 4, true>(p.at, lds, &s_last, b % p.at.n_kv, b / p.at.n_kv, 0, p.done);
+    return;
+  }
+  const int t = b - p.n_attn;  // output column tile
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
+  OSTAMP(0);
+  // ---- the whole weight slice of the tile, now: wave w holds k-steps [32 w, 32 w + 32)
+  bf16x8 wv[4][8];
+  {
+    const bf16x8 *base = p.wo + ((size_t)t * p.KS + 32 * w) * 64;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      int nf = p.KS - 32 * w - 8 * c;
+      nf = nf < 0 ? 0 : (nf > 8 ? 8 : nf);
+      load_ksteps<8>(wv[c], base + c * 8 * 64, nf, l);
+    }
+  }
+#ifdef DFL_ATTN_STAMPS
+  OSTAMP(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  OSTAMP(2);  // weights landed
+#endif
+  // ---- wait (bounded) until every head's output is complete
+  if (tid == 0) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    const int *mine = p.done + (t & 31) * 32;  // 8 pollers per replica
+    while (__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p.done_target) {
+      __builtin_amdgcn_s_sleep(8);
+      if (__builtin_amdgcn_s_memrealtime() - t0 > 200000ull) {  // 2 ms of the 100 MHz clock
+        *p.fail = 1;
+        break;
+      }
+    }
+  }
+  OSTAMP(3);  // heads done (lane 0's poll)
+  __syncthreads();
+  // ---- the activation fragments (frag16 of the 16 rows: k-step ks = 1 KiB at out_frag + 64 ks), sc1 loads: 128 KB per
+  // workgroup, 4.3 us; an agent-scope acquire fence (L2 invalidate) + plain loads instead took 11 us
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  {
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16x8 *>(p.at.out_frag), 0, p.KS * 1024, 0x00020000);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      bf16x8 xv[8];
+#pragma unroll
+      for (int f = 0; f < 8; ++f)  // (k-steps past KS: out of the descriptor's range, read as zeros)
+        xv[f] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rx, ((32 * w + 8 * c + f) * 64 + l) * 16, 0, 16));
+#pragma unroll
+      for (int f = 0; f < 8; ++f) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[c][f], xv[f], acc, 0, 0, 0);
+    }
+  }
+  float *red = reinterpret_cast<float *>(lds);  // [4 waves][256]
+  *reinterpret_cast<f32x4 *>(&red[w * 256 + l * 4]) = acc;
+  OSTAMP(4);  // activations loaded, MFMAs done (wave 0)
+  __syncthreads();
+  OSTAMP(5);
+  {  // thread (row m, column nl) of the tile; D layout of the MFMA as in gemm_skinny.hip
+    const int m = tid >> 4, nl = tid & 15;
+    const int idx = 4 * (m + 16 * (nl >> 2)) + (nl & 3);
+    float s = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww) s += red[ww * 256 + idx];
+    const int n = t * 16 + nl;
+    const float v = rbf(s);  // the Linear's bf16 output (model/dflash.py:101)
+    bf16_t *hp = p.h_io + (int64_t)m * p.ldh + n;
+    const float hn = rbf(bf2f(*hp) + v);  // residual add (:140)
+    *hp = f2bf(hn);
+    const float qs = row_sum16(hn * hn);
+    if (nl == 0 && p.ss_out) p.ss_out[t * 16 + m] = qs;
+  }
+#ifdef DFL_ATTN_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  OSTAMP(6);
+  // ---- the last o_proj workgroup past its wait re-arms the counters for the next launch
+  if (tid == 0) {
+    const int k = __hip_atomic_fetch_add(p.o_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k == p.ntiles - 1) {
+      for (int r = 0; r < 32; ++r) __hip_atomic_store(p.done + r * 32, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(p.o_done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 }  // namespace
@@ -618,6 +789,14 @@ __global__ __launch_bounds__(512) void k_attn_head(HeadAttnArgs a) {
 #ifdef DFL_ATTN_STAMPS
 extern "C" int dfl_debug_read_head_stamps(unsigned long long *host_out) {
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_hstamps), sizeof(unsigned long long) * 16);
+}
+extern "C" int dfl_debug_read_attn_max(unsigned long long *host_out) {  // reads and clears
+  const int rc = (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_amax), sizeof(unsigned long long) * 16);
+  unsigned long long z[16] = {};
+  return rc ? rc : (int)hipMemcpyToSymbol(HIP_SYMBOL(g_amax), z, sizeof(z));
+}
+extern "C" int dfl_debug_read_oproj_stamps(unsigned long long *host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_ostamps), sizeof(unsigned long long) * 16);
 }
 #endif
 
@@ -627,13 +806,23 @@ extern "C" int64_t dfl_attn_head_ws_bytes(int n_q, int max_splits, int q_tiles) 
 }
 
 namespace {
+// o_proj behind the attention stage in the same launch (dfl_attn_head_oproj)
+struct OprojTail {
+  const void *wo;
+  int q_dim, H;
+  void *h_io;
+  int64_t ldh;
+  float *ss_out;
+  int32_t *sync;
+};
+
 int attn_head_launch(const void *xq, int64_t ldq, int q_col, int k_col, int v_col, const void *xc, int64_t ldc, int ck_col,
                      int cv_col, int n_q, int n_kv, const void *q_norm_w, const void *k_norm_w, float eps,
                      const void *cos_tab, const void *sin_tab, int max_pos, void *kcache, void *vcache, int cache_rows,
                      float scale, int causal, const int32_t *dyn, int S, int tau, int bs, int pos0, int q_tiles, void *ws,
                      int max_splits, void *out_frag, int64_t out_tile_stride, int n_cand, int64_t xq_cand_stride,
                      int64_t out_cand_stride, void *k_out, void *v_out, int64_t kv_out_cand_stride, int out_rows,
-                     int dyn_cand_stride, int64_t cache_cand_stride, void *stream) {
+                     int dyn_cand_stride, int64_t cache_cand_stride, void *stream, const OprojTail *tail = nullptr) {
   DFL_REQUIRE(xq && cos_tab && sin_tab && kcache && vcache && out_frag && ws, "dfl_attn_head: null pointer");
   DFL_REQUIRE((q_norm_w == nullptr) == (k_norm_w == nullptr), "dfl_attn_head: give both norm weights or neither");
   DFL_REQUIRE(n_q > 0 && n_kv > 0 && n_q % n_kv == 0, "dfl_attn_head: bad head counts (n_q=%d n_kv=%d)", n_q, n_kv);
@@ -664,10 +853,13 @@ int attn_head_launch(const void *xq, int64_t ldq, int q_col, int k_col, int v_co
   // scripts/dbg_attn_head_stamps.py; the defaults are the measured choice)
   static const int knob_tiles = [] { const char *e = getenv("DFL_ATTN_HEAD_TILES"); return e ? atoi(e) : 8; }();
   static const int knob_wgs = [] { const char *e = getenv("DFL_ATTN_HEAD_WGS"); return e ? atoi(e) : 224; }();
-  const int tiles = knob_tiles < 1 ? 1 : knob_tiles;
+  static const int knob_wgs4 = [] { const char *e = getenv("DFL_ATTN_OPROJ_WGS"); return e ? atoi(e) : 256; }();
+  static const int knob_tiles4 = [] { const char *e = getenv("DFL_ATTN_OPROJ_TILES"); return e ? atoi(e) : 4; }();
+  // (with the o_proj tail: 4-wave workgroups, two per CU; 256 attention + H/16 o_proj workgroups fill the 512 slots)
+  const int tiles = tail ? (knob_tiles4 < 1 ? 1 : knob_tiles4) : (knob_tiles < 1 ? 1 : knob_tiles);
   int ns_old = (nt + tiles - 1) / tiles;
   // (several blocks per launch: up to two rounds of workgroups, or every block would be left with one split)
-  int budget = knob_wgs * (n_cand > 1 ? 2 : 1) / (n_q * n_cand) - 1;
+  int budget = (tail ? knob_wgs4 : knob_wgs * (n_cand > 1 ? 2 : 1)) / (n_q * n_cand) - 1;
   budget = budget < 1 ? 1 : budget;
   ns_old = ns_old > budget ? budget : ns_old;
   ns_old = ns_old > max_splits - 1 ? max_splits - 1 : ns_old;
@@ -719,6 +911,24 @@ int attn_head_launch(const void *xq, int64_t ldq, int q_col, int k_col, int v_co
   a.cache_cand_stride = cache_cand_stride;
   const dim3 grid(n_kv, G * (ns_old + 1), n_cand);
   hipStream_t st = (hipStream_t)stream;
+  if (tail) {
+    AttnOArgs p{};
+    p.at = a;
+    p.n_attn = n_kv * G * (ns_old + 1);
+    p.wo = (const bf16x8 *)tail->wo;
+    p.KS = tail->q_dim / 32;
+    p.ntiles = tail->H / 16;
+    p.h_io = (bf16_t *)tail->h_io;
+    p.ldh = tail->ldh;
+    p.ss_out = tail->ss_out;
+    p.done = tail->sync;
+    p.o_done = tail->sync + 1024;
+    p.fail = tail->sync + 1025;
+    p.done_target = n_q;
+    hipLaunchKernelGGL(k_attn_oproj, dim3(p.n_attn + p.ntiles), dim3(256), 0, st, p);
+    DFL_CHECK_LAUNCH("dfl_attn_head_oproj");
+    return DFL_OK;
+  }
   if (q_tiles == 1)
     hipLaunchKernelGGL(k_attn_head<1>, grid, dim3(512), 0, st, a);
   else
@@ -737,6 +947,22 @@ extern "C" int dfl_attn_head(const void *xq, int64_t ldq, int q_col, int k_col, 
   return attn_head_launch(xq, ldq, q_col, k_col, v_col, xc, ldc, ck_col, cv_col, n_q, n_kv, q_norm_w, k_norm_w, eps, cos_tab,
                           sin_tab, max_pos, kcache, vcache, cache_rows, scale, causal, dyn, S, tau, bs, pos0, q_tiles, ws,
                           max_splits, out_frag, out_tile_stride, 1, 0, 0, nullptr, nullptr, 0, 0, 0, 0, stream);
+}
+
+extern "C" int dfl_attn_head_oproj(const void *xq, int64_t ldq, int q_col, int k_col, int v_col, const void *xc, int64_t ldc,
+                                   int ck_col, int cv_col, int n_q, int n_kv, const void *q_norm_w, const void *k_norm_w,
+                                   float eps, const void *cos_tab, const void *sin_tab, int max_pos, void *kcache,
+                                   void *vcache, int cache_rows, float scale, int causal, const int32_t *dyn, int S, int tau,
+                                   int bs, int pos0, void *ws, int max_splits, void *attn_frag, const void *wo_packed, int H,
+                                   void *h_io, int64_t ldh, float *ss_out, int32_t *sync, void *stream) {
+  DFL_REQUIRE(wo_packed && h_io && sync, "dfl_attn_head_oproj: null pointer");
+  DFL_REQUIRE(H > 0 && H % 16 == 0 && ldh >= H && n_q * 128 <= 4096 && bs <= 16 && tau + bs <= 32,
+              "dfl_attn_head_oproj: H=%d q_dim=%d tau=%d bs=%d outside the kernel's range (q_dim <= 4096, tau + bs <= 32)", H,
+              n_q * 128, tau, bs);
+  const OprojTail tail{wo_packed, n_q * 128, H, h_io, ldh, ss_out, sync};
+  return attn_head_launch(xq, ldq, q_col, k_col, v_col, xc, ldc, ck_col, cv_col, n_q, n_kv, q_norm_w, k_norm_w, eps, cos_tab,
+                          sin_tab, max_pos, kcache, vcache, cache_rows, scale, causal, dyn, S, tau, bs, pos0, 1, ws, max_splits,
+                          attn_frag, 0, 1, 0, 0, nullptr, nullptr, 0, 0, 0, 0, stream, &tail);
 }
 
 extern "C" int dfl_attn_head_cand(const void *xq, int64_t ldq, int q_col, int k_col, int v_col, int n_cand,

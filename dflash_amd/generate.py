@@ -297,6 +297,9 @@ def run_decode(model, target, input_ids: torch.Tensor, *, mask_token_id: int, ma
             break
 
     output_ids = s.finish()
+    for m in (model, target):   # opt-in fused launches leave a flag instead of hanging when their wait runs out
+        if getattr(m, "fuse_oproj", False):
+            m.raise_if_failed()
     num_output_tokens = output_ids.shape[1] - s.n_in
     total_decode_time = cuda_time() - decode_start
     profile_summary = None

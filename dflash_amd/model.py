@@ -80,6 +80,7 @@ class DFlashDraftModel:
         self._rope = None
         # "head": dfl_attn_head on finished bf16 q/k/v rows (round 2); "fused": round-1 stage on fp32 partials
         self.attn_impl = "head"
+        self.fuse_oproj = False    # True: attention + o_proj in one launch (dfl_attn_head_oproj); measured slower
         self.wide_prefill = True   # False: the round-1 context prefill in 16-row groups (kept for A/B timing and tests)
 
     # ------------------------------------------------------------------ weights
@@ -177,6 +178,7 @@ class DFlashDraftModel:
                 xq=torch.zeros(16 * NT, nqkv, dtype=BF16, device=d),
                 xc=torch.zeros(16, c.num_hidden_layers * 2 * c.kv_dim, dtype=BF16, device=d),
                 head_ws=ops.attn_head_ws(c.num_attention_heads, self.max_splits, NT, d),
+                sync=torch.zeros(ops.ATTN_OPROJ_SYNC_WORDS, dtype=torch.int32, device=d),
             )
             # row sources of the fused pipeline (pointers are fixed for the model's lifetime), one per block tile:
             # the GEMM that consumes a normalised activation applies the RMSNorm itself
@@ -298,6 +300,13 @@ class DFlashDraftModel:
                                        ctx_rows_override=rows, row_base=g0)
         cache.length = S + n
 
+
+    def raise_if_failed(self) -> None:
+        """fuse_oproj only: a dfl_attn_head_oproj launch whose o_proj workgroups gave up waiting (2 ms) leaves a flag."""
+        if self.fuse_oproj and self._ws is not None and int(self._ws["sync"][ops.ATTN_OPROJ_FAIL_WORD]) != 0:
+            self._ws["sync"].zero_()
+            raise RuntimeError("dfl_attn_head_oproj: an o_proj workgroup gave up waiting for the attention stage")
+
     def draft_block(self, cache: DFlashKVCache, *, th_rows: Optional[torch.Tensor], tau: int, bs: int, pos0: int,
                     block_ids: Optional[torch.Tensor] = None, embed: Optional[torch.Tensor] = None,
                     noise: Optional[torch.Tensor] = None, append: bool = True) -> list:
@@ -340,19 +349,25 @@ class DFlashDraftModel:
             for t, dt in tiles:
                 ops.embed_rows(embed, block_ids[16 * t:], ws["h"][16 * t:], H, ws["ss_emb"][16 * t:], dt, ops.DYN_BS)
         hrow = [ws["h"][16 * t:16 * t + 16] for t in range(2)]
+        fuse_o = self.fuse_oproj and head and len(tiles) == 1 and c.q_dim <= 4096
         for i, lw in enumerate(L):
             x1 = src["ln1_first"] if i == 0 else src["ln1"][i]
             if head:
                 for t, dt in tiles:
                     ops.gemm_resid(lw["qkv"], x1[t], nqkv, H, ws["xq"][16 * t:], add_residual=False, dyn=dt)
-                ops.attn_head(xq=ws["xq"], q_col=0, k_col=c.q_dim, v_col=c.q_dim + c.kv_dim,
-                              xc=ws["xc"] if tau > 0 else None, ck_col=i * 2 * c.kv_dim,
-                              cv_col=i * 2 * c.kv_dim + c.kv_dim, n_q=c.num_attention_heads,
-                              n_kv=c.num_key_value_heads, q_norm_w=lw["q_norm"], k_norm_w=lw["k_norm"],
-                              eps=c.rms_norm_eps, cos_tab=cos, sin_tab=sin, kcache=cache.k[i], vcache=cache.v[i],
-                              scale=c.head_dim ** -0.5, causal=False, S=S, tau=tau, bs=bs, pos0=pos0,
-                              ws=ws["head_ws"], max_splits=self.max_splits, out_frag=ws["attn_frag"],
-                              q_tiles=len(tiles), out_tile_stride=ws["attn_frag"].stride(0))
+                kw = dict(xq=ws["xq"], q_col=0, k_col=c.q_dim, v_col=c.q_dim + c.kv_dim,
+                          xc=ws["xc"] if tau > 0 else None, ck_col=i * 2 * c.kv_dim,
+                          cv_col=i * 2 * c.kv_dim + c.kv_dim, n_q=c.num_attention_heads,
+                          n_kv=c.num_key_value_heads, q_norm_w=lw["q_norm"], k_norm_w=lw["k_norm"],
+                          eps=c.rms_norm_eps, cos_tab=cos, sin_tab=sin, kcache=cache.k[i], vcache=cache.v[i],
+                          scale=c.head_dim ** -0.5, causal=False, S=S, tau=tau, bs=bs, pos0=pos0,
+                          ws=ws["head_ws"], max_splits=self.max_splits)
+                if fuse_o:
+                    ops.attn_head_oproj(**kw, attn_frag=ws["attn_frag"][0], wo=lw["o"], H=H, h_io=hrow[0],
+                                        ss_out=ws["ss_h"][0], sync=ws["sync"])
+                else:
+                    ops.attn_head(**kw, out_frag=ws["attn_frag"], q_tiles=len(tiles),
+                                  out_tile_stride=ws["attn_frag"].stride(0))
             else:
                 ops.gemm_f32(lw["qkv"], src["ctx"], x1[0], 2, nqkv, H, self.ks_qkv, ws["part"], dyn)
                 # one launch: q/k-norm + RoPE + KV append + attention + split merge
@@ -363,8 +378,9 @@ class DFlashDraftModel:
                                vcache=cache.v[i], dyn=dyn, scale=c.head_dim ** -0.5, kv_len_max=S + tau + bs,
                                ws=ws["attn_ws"], max_splits=self.max_splits, out_frag=ws["attn_frag"][0])
             for t, dt in tiles:
-                ops.gemm_resid(lw["o"], src["attn"][t], H, c.q_dim, hrow[t], add_residual=True, ss_out=ws["ss_h"][t],
-                               dyn=dt)
+                if not fuse_o:
+                    ops.gemm_resid(lw["o"], src["attn"][t], H, c.q_dim, hrow[t], add_residual=True, ss_out=ws["ss_h"][t],
+                                   dyn=dt)
             for t, dt in tiles:
                 ops.gemm_silu_mul(lw["gu"], src["ln2"][i][t], I, H, ws["act_frag"][t], dt)
             for t, dt in tiles:

@@ -279,6 +279,35 @@ def attn_head(*, xq: torch.Tensor, q_col: int, k_col: int, v_col: int, n_q: int,
         _p(out_frag, BF16, "out_frag"), out_tile_stride, _stream()), "dfl_attn_head")
 
 
+ATTN_OPROJ_SYNC_WORDS = 1056   # DFL_ATTN_OPROJ_SYNC_WORDS: 32 counter replicas on their own lines + bookkeeping
+ATTN_OPROJ_FAIL_WORD = 1025
+
+
+def attn_head_oproj(*, xq: torch.Tensor, q_col: int, k_col: int, v_col: int, n_q: int, n_kv: int, q_norm_w, k_norm_w, eps,
+                    cos_tab, sin_tab, kcache, vcache, scale: float, causal: bool, S: int, tau: int, bs: int, pos0: int,
+                    ws, max_splits: int, attn_frag: torch.Tensor, wo, H: int, h_io: torch.Tensor, ss_out, sync,
+                    xc: Optional[torch.Tensor] = None, ck_col: int = 0, cv_col: int = 0,
+                    dyn: Optional[torch.Tensor] = None) -> None:
+    """attn_head (one query tile) + the o_proj / residual GEMM behind it in one launch; sync: int32[ATTN_OPROJ_SYNC_WORDS],
+    zeroed once (sync[ATTN_OPROJ_FAIL_WORD] != 0 afterwards: the launch gave up waiting, h_io is invalid)."""
+    assert xq.is_cuda and xq.dtype == BF16 and xq.dim() == 2 and xq.stride(1) == 1 and xq.shape[0] >= min(bs, 16)
+    assert kcache.shape == vcache.shape and kcache.dim() == 3 and kcache.shape[2] == 128
+    assert h_io.is_cuda and h_io.dtype == BF16 and h_io.stride(1) == 1 and h_io.shape[0] >= 16
+    assert sync.dtype == I32 and sync.numel() >= ATTN_OPROJ_SYNC_WORDS and attn_frag.numel() >= 16 * n_q * 128
+    assert ss_out is None or ss_out.numel() >= H
+    xcp, ldc = None, 0
+    if xc is not None:
+        assert xc.is_cuda and xc.dtype == BF16 and xc.dim() == 2 and xc.stride(1) == 1 and xc.shape[0] >= tau
+        xcp, ldc = xc.data_ptr(), xc.stride(0)
+    check(lib().dfl_attn_head_oproj(
+        xq.data_ptr(), xq.stride(0), q_col, k_col, v_col, xcp, ldc, ck_col, cv_col, n_q, n_kv,
+        _p(q_norm_w, BF16, "q_norm_w"), _p(k_norm_w, BF16, "k_norm_w"), eps, _p(cos_tab, BF16, "cos"),
+        _p(sin_tab, BF16, "sin"), cos_tab.shape[0], _p(kcache, BF16, "kcache"), _p(vcache, BF16, "vcache"),
+        kcache.shape[1], scale, int(causal), _p(dyn, I32, "dyn"), S, tau, bs, pos0, _p(ws), max_splits,
+        _p(attn_frag, BF16, "attn_frag"), _p(wo, BF16, "wo"), H, h_io.data_ptr(), h_io.stride(0), _p(ss_out, F32, "ss_out"),
+        _p(sync, I32, "sync"), _stream()), "dfl_attn_head_oproj")
+
+
 def attn_head_cand(*, xq: torch.Tensor, q_col: int, k_col: int, v_col: int, n_q: int, n_kv: int, q_norm_w, k_norm_w, eps,
                    cos_tab, sin_tab, kcache, vcache, scale: float, S: int, bs: int, ws, max_splits: int,
                    out_frag: torch.Tensor, k_out: torch.Tensor, v_out: torch.Tensor) -> None:

@@ -57,6 +57,9 @@ class NativeTarget:
         if attn_impl not in ("head", "fused"):
             raise ValueError("attn_impl must be 'head' or 'fused'")
         self.attn_impl = attn_impl
+        # True: attention + o_proj in one launch (dfl_attn_head_oproj) where its range allows.  Measured SLOWER than the
+        # two launches (23.2 vs 20.3 us per layer): off by default, kept for A/B and tests
+        self.fuse_oproj = False
         cfg = hf_model.config
         self.hf = hf_model
         self.model = hf_model.model
@@ -148,6 +151,7 @@ class NativeTarget:
                        q=z(self.n_q, 16, 128), part=z(npart, dt=torch.float32),
                        attn_ws=ops.attn_fused_ws(self.n_q, self.n_kv, max_splits, dev), argmax_ws=ops.argmax_ws(dev),
                        xq=z(16 * NT, self.nqkv), head_ws=ops.attn_head_ws(self.n_q, max_splits, NT, dev),
+                       sync=torch.zeros(ops.ATTN_OPROJ_SYNC_WORDS, dtype=torch.int32, device=dev),
                        post=torch.zeros(16 * NT, dtype=torch.int64, device=dev))
         self.is_moe = any("gu_e" in lw for lw in self.layers)
         if self.is_moe:
@@ -245,6 +249,13 @@ class NativeTarget:
 
     # ---- the verify forward on the kernels
     @torch.inference_mode()
+
+    def raise_if_failed(self) -> None:
+        """fuse_oproj only: a dfl_attn_head_oproj launch whose o_proj workgroups gave up waiting (2 ms) leaves a flag."""
+        if self.fuse_oproj and int(self.ws["sync"][ops.ATTN_OPROJ_FAIL_WORD]) != 0:
+            self.ws["sync"].zero_()
+            raise RuntimeError("dfl_attn_head_oproj: an o_proj workgroup gave up waiting for the attention stage")
+
     def verify(self, block_ids: torch.Tensor, start: int, cache: TargetKVCache, *, tap_layers: Sequence[int] = (),
                temperature: float = 0.0, logits_out: Optional[torch.Tensor] = None,
                taps_out: Optional[torch.Tensor] = None):
@@ -287,6 +298,7 @@ class NativeTarget:
         hrow = [ws["h"][16 * t:16 * t + 16] for t in range(2)]
         for t, dt in tiles:
             ops.embed_rows(self.embed, block_ids[16 * t:], hrow[t], H, ws["ss_emb"][16 * t:], dt, ops.DYN_BS)
+        fuse_o = self.fuse_oproj and self.attn_impl == "head" and len(tiles) == 1 and self.q_dim <= 4096
         prev_moe = False   # an MoE layer leaves its successor's input already normalised (frag16 in ws["xn1"])
         for i, lw in enumerate(Ls):
             x1 = src["xn1"] if prev_moe else src["ln1"][i]
@@ -295,11 +307,15 @@ class NativeTarget:
                 # one launch: q/k-norm + RoPE + append + causal attention + split merge
                 for t, dt in tiles:
                     ops.gemm_resid(lw["qkv"], x1[t], self.nqkv, H, ws["xq"][16 * t:], add_residual=False, dyn=dt)
-                ops.attn_head(xq=ws["xq"], q_col=0, k_col=self.q_dim, v_col=self.q_dim + self.kv_dim, n_q=self.n_q,
-                              n_kv=self.n_kv, q_norm_w=lw["q_norm"], k_norm_w=lw["k_norm"], eps=self.eps, cos_tab=cos,
-                              sin_tab=sin, kcache=cache.k[i], vcache=cache.v[i], scale=128 ** -0.5, causal=True,
-                              S=start, tau=0, bs=bs, pos0=start, ws=ws["head_ws"], max_splits=self.max_splits,
-                              out_frag=ws["attn"], q_tiles=len(tiles), out_tile_stride=ws["attn"].stride(0))
+                kw = dict(xq=ws["xq"], q_col=0, k_col=self.q_dim, v_col=self.q_dim + self.kv_dim, n_q=self.n_q,
+                          n_kv=self.n_kv, q_norm_w=lw["q_norm"], k_norm_w=lw["k_norm"], eps=self.eps, cos_tab=cos,
+                          sin_tab=sin, kcache=cache.k[i], vcache=cache.v[i], scale=128 ** -0.5, causal=True,
+                          S=start, tau=0, bs=bs, pos0=start, ws=ws["head_ws"], max_splits=self.max_splits)
+                if fuse_o:
+                    ops.attn_head_oproj(**kw, attn_frag=ws["attn"][0], wo=lw["o"], H=H, h_io=hrow[0],
+                                        ss_out=ws["ss_h"][0], sync=ws["sync"])
+                else:
+                    ops.attn_head(**kw, out_frag=ws["attn"], q_tiles=len(tiles), out_tile_stride=ws["attn"].stride(0))
             else:
                 ops.gemm_f32(lw["qkv"], x1[0], None, 1, self.nqkv, H, self.ks_qkv, ws["part"], dyn)
                 ops.attn_fused(qkv=ws["part"], nsplit=self.ks_qkv, split_stride=16 * self.nqkv, ld=self.nqkv, q_col=0,
@@ -309,8 +325,9 @@ class NativeTarget:
                                scale=128 ** -0.5, kv_len_max=start + bs, ws=ws["attn_ws"],
                                max_splits=self.max_splits, out_frag=ws["attn"][0], causal=True)
             for t, dt in tiles:
-                ops.gemm_resid(lw["o"], src["attn"][t], H, self.q_dim, hrow[t], add_residual=True,
-                               ss_out=ws["ss_h"][t], dyn=dt)
+                if not fuse_o:
+                    ops.gemm_resid(lw["o"], src["attn"][t], H, self.q_dim, hrow[t], add_residual=True,
+                                   ss_out=ws["ss_h"][t], dyn=dt)
             # every slot j with tap_layers[j] == i: build_target_layer_ids repeats layers for shallow
             # targets and the reference concatenates the same state twice (model/utils.py:16-25)
             sl = [j for j, l in enumerate(tap_layers) if l == i]

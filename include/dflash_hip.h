@@ -227,6 +227,22 @@ int dfl_attn_head(const void *xq, int64_t ldq, int q_col, int k_col, int v_col, 
                   float scale, int causal, const int32_t *dyn, int S, int tau, int bs, int pos0, int q_tiles,
                   void *ws, int max_splits, void *out_frag, int64_t out_tile_stride, void *stream);
 
+/* dfl_attn_head (q_tiles = 1) AND the o_proj + residual GEMM that follows it (model/dflash.py:101,140; for the
+ * target tf:modeling_qwen3.py o_proj) in ONE launch: besides the attention workgroups the grid carries one workgroup
+ * per 16-column tile of o_proj, which pulls its weight slice into registers while the attention runs (the stage
+ * leaves HBM idle), waits for the heads' outputs (bounded: 2 ms), and finishes the GEMM with dfl_gemm_resid's
+ * epilogue: h_io [16][ldh] <- bf16(h_io + bf16(attn . Wo^T)), ss_out [H/16][16] partial sums of squares.
+ * Range: q_dim = n_q * 128 <= 4096, bs <= 16, tau + bs <= 32, H % 16 == 0.  attn_frag: frag16 of the attention output
+ * (16 * q_dim bf16; rows >= bs are written as zeros).  sync: DFL_ATTN_OPROJ_SYNC_WORDS int32, ZEROED once; sync[1025] != 0 after a launch means an
+ * o_proj workgroup gave up waiting and h_io is invalid (the Python layer raises; it cannot happen on an idle GPU). */
+#define DFL_ATTN_OPROJ_SYNC_WORDS 1056
+int dfl_attn_head_oproj(const void *xq, int64_t ldq, int q_col, int k_col, int v_col, const void *xc, int64_t ldc,
+                        int ck_col, int cv_col, int n_q, int n_kv, const void *q_norm_w, const void *k_norm_w, float eps,
+                        const void *cos_tab, const void *sin_tab, int max_pos, void *kcache, void *vcache,
+                        int cache_rows, float scale, int causal, const int32_t *dyn, int S, int tau, int bs, int pos0,
+                        void *ws, int max_splits, void *attn_frag, const void *wo_packed, int H, void *h_io,
+                        int64_t ldh, float *ss_out, int32_t *sync, void *stream);
+
 /* ---- multi-candidate verify (benchmark_candidate_solutions.py) ----
  * Several drafts of ONE block are verified against ONE cached prefix and the best is kept (:570-618).
  *

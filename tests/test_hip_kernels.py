@@ -577,6 +577,63 @@ def test_attn_head_two_query_tiles(ops, n_q, n_kv, S, tau, bs, causal):
     assert (got - ref).abs().max() <= 2 ** -6 * ref.abs().max()
 
 
+@pytest.mark.parametrize("n_q,n_kv,H,S,tau,bs,causal", [(32, 8, 4096, 1024, 0, 16, True), (32, 8, 4096, 1031, 7, 16, False),
+                                                        (16, 4, 1024, 300, 0, 5, True), (8, 8, 512, 0, 16, 16, False),
+                                                        (32, 4, 2560, 4100, 3, 9, True), (4, 1, 96, 40, 0, 16, True)])
+def test_attn_head_oproj_equals_two_launches(ops, n_q, n_kv, H, S, tau, bs, causal):
+    """dfl_attn_head_oproj (attention stage + o_proj/residual GEMM in one launch: o_proj workgroups hold their weight
+    slice in registers and wait for the heads) against dfl_attn_head followed by dfl_gemm_resid on the same inputs:
+    appended K/V bit-identical, attention rows < bs within split-order rounding, rows >= bs zero, h within bf16
+    rounding of a different K-summation order, sums of squares consistent with h; the launch leaves its counters
+    re-armed (run twice) and never raises its failure flag."""
+    from dflash_amd.model import _rope_tables
+    g = gen(S + n_q + bs + H)
+    ld = (n_q + 2 * n_kv) * 128
+    x = torch.randn(32, ld, generator=g).to(BF16).to(dev())
+    qw = (1 + 0.1 * torch.randn(128, generator=g)).to(BF16).to(dev())
+    kw = (1 + 0.1 * torch.randn(128, generator=g)).to(BF16).to(dev())
+    cos, sin = _rope_tables(128, 1e6, 16384, dev())
+    rows = S + tau + bs + 8
+    k0 = torch.randn(n_kv, rows, 128, generator=g).to(BF16).to(dev())
+    v0 = torch.randn(n_kv, rows, 128, generator=g).to(BF16).to(dev())
+    wo = (torch.randn(H, n_q * 128, generator=g) * (n_q * 128) ** -0.5).to(BF16).to(dev())
+    wop = ops.pack_weight(wo)
+    h0 = torch.randn(16, H, generator=g).to(BF16).to(dev())
+    kw_args = dict(xq=x[16:], q_col=0, k_col=n_q * 128, v_col=(n_q + n_kv) * 128, xc=x[:16], ck_col=n_q * 128,
+                   cv_col=(n_q + n_kv) * 128, n_q=n_q, n_kv=n_kv, q_norm_w=qw, k_norm_w=kw, eps=1e-6, cos_tab=cos,
+                   sin_tab=sin, scale=128 ** -0.5, causal=causal, S=S, tau=tau, bs=bs, pos0=S, max_splits=16)
+    dyn = torch.zeros(8, dtype=torch.int32, device=dev())
+    ops.set_dyn(dyn, S, tau, bs, S)
+    # two launches
+    k1, v1, h1 = k0.clone(), v0.clone(), h0.clone()
+    out1 = torch.zeros(16 * n_q * 128, dtype=BF16, device=dev())
+    ss1 = torch.zeros(H, dtype=torch.float32, device=dev())
+    ops.attn_head(**kw_args, kcache=k1, vcache=v1, ws=ops.attn_head_ws(n_q, 16, 1, dev()), out_frag=out1)
+    ops.gemm_resid(wop, ops.rows_frag(out1), H, n_q * 128, h1, add_residual=True, ss_out=ss1, dyn=dyn)
+    # one launch, twice
+    hws = ops.attn_head_ws(n_q, 16, 1, dev())
+    sync = torch.zeros(ops.ATTN_OPROJ_SYNC_WORDS, dtype=torch.int32, device=dev())
+    for _ in range(2):
+        k2, v2, h2 = k0.clone(), v0.clone(), h0.clone()
+        out2 = torch.full((16 * n_q * 128,), float("nan"), dtype=BF16, device=dev())
+        ss2 = torch.full((H,), float("nan"), dtype=torch.float32, device=dev())
+        ops.attn_head_oproj(**kw_args, kcache=k2, vcache=v2, ws=hws, attn_frag=out2, wo=wop, H=H, h_io=h2, ss_out=ss2,
+                            sync=sync)
+        assert int(sync.abs().sum()) == 0
+        assert torch.equal(k1, k2) and torch.equal(v1, v2)
+        a, b = unfrag(out1, n_q * 128).float(), unfrag(out2, n_q * 128).float()
+        assert torch.isfinite(b).all() and (b[bs:] == 0).all()
+        assert (a[:bs] - b[:bs]).abs().max() <= 2 ** -6 * a[:bs].abs().max()
+        # o_proj of the launch's OWN attention rows, fp32
+        want = (h0.float() + (b @ wo.float().T).to(BF16).float()).to(BF16).float()
+        d = (h2.float() - want).abs()
+        assert d.max() <= 2 ** -6 * want.abs().max() and (d > 0).float().mean() < 0.05
+        assert (h2.float() - h1.float())[:bs].abs().max() <= 2 ** -5 * h1.float().abs().max()
+        assert torch.equal(h2[bs:], h0[bs:])
+        got_ss = ss2.view(H // 16, 16).sum(0)
+        assert torch.allclose(got_ss, h2.float().pow(2).sum(-1), rtol=1e-4)
+
+
 # ------------------------------------------------------------------ integer side, golden
 def test_argmax_golden(ops):
     z = np.load(os.path.join(H.GOLDEN, "argmax.npz"))

@@ -276,6 +276,45 @@ def test_native_target_end_to_end_lossless_walk():
     assert runs["native"].acceptance_lengths == exp
 
 
+def test_fused_attention_oproj_launch_is_equivalent():
+    """fuse_oproj = True (dfl_attn_head_oproj: attention stage + o_proj in one launch, opt-in because it measured
+    slower): the native verify's posterior ids and taps and the draft's block tokens agree with the two-launch
+    path within the usual tolerances, the lossless walk still holds, and no launch raised its failure flag."""
+    from dflash_amd import NativeTarget, dflash_generate
+    from dflash_amd.synthetic import greedy_walk, impose_greedy_walk
+    cfg = H.tiny_cfg()
+    hf = _tiny_hf()
+    perm = impose_greedy_walk(hf, seed=6)
+    prompt = torch.randint(0, 2000, (1, 41), generator=torch.Generator().manual_seed(9)).to(dev())
+    G = greedy_walk(perm, prompt, 120).to(dev())
+    outs = {}
+    for fuse in (False, True):
+        m = make_model(cfg)
+        m.fuse_oproj = fuse
+        tgt = NativeTarget(hf)
+        tgt.fuse_oproj = fuse
+        r = dflash_generate(m, tgt, prompt, cfg.mask_token_id, 72, 16, None, 0.0)
+        assert r.output_ids[0].tolist() == G[:41 + 72].tolist(), fuse
+        outs[fuse] = r
+        if fuse:
+            assert int(tgt.ws["sync"].abs().sum()) == 0 and int(m._ws["sync"].abs().sum()) == 0
+    assert outs[True].output_ids.tolist() == outs[False].output_ids.tolist()
+    # one verify pass, state by state
+    ids = G[:41][None]
+    res = {}
+    for fuse in (False, True):
+        tgt = NativeTarget(hf)
+        tgt.fuse_oproj = fuse
+        cache = tgt.new_cache(256)
+        tgt.prefill(ids[:, :30], cache)
+        post, taps = tgt.verify(ids[0, 30:41].contiguous(), 30, cache, tap_layers=[1, 2])
+        tgt.raise_if_failed()
+        res[fuse] = (post.clone(), taps[:11].clone(), cache.k[3][:, :41].clone())
+    assert torch.equal(res[True][0], res[False][0])
+    H.assert_close("taps, one launch vs two", res[True][1], res[False][1])
+    H.assert_close("K rows layer 3, one launch vs two", res[True][2], res[False][2], max_rel=H.KV_MAX_REL)
+
+
 def test_temperature_path_with_sharp_logits():
     """T = 0.7 (BASELINE config 4's sampling path): softmax + torch.multinomial on the
     posterior, acceptance on the device.  With the scripted target's +-10 logits the
