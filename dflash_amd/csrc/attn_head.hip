@@ -276,7 +276,7 @@ __device__ __forceinline__ void attn_head_body(const HeadAttnArgs &a, char *lds,
   bf16x8 kA[2][4], vA[8], kB[2][4], vB[8];
   // all loads of a tile are unconditional with clamped rows (they batch; rows >= S are masked
   // below and never touch memory another workgroup writes in this launch)
-  auto fetch = [&](bf16x8(&kf)[2][4], bf16x8(&vr)[8], int t) {
+  auto fetch_k = [&](bf16x8(&kf)[2][4], int t) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       int row = t * 32 + u * 16 + qi;
@@ -285,6 +285,8 @@ __device__ __forceinline__ void attn_head_body(const HeadAttnArgs &a, char *lds,
       for (int s = 0; s < 4; ++s)
         kf[u][s] = *reinterpret_cast<const bf16x8 *>(kbase + (int64_t)row * 128 + s * 32 + g * 8);
     }
+  };
+  auto fetch_v = [&](bf16x8(&vr)[8], int t) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int c = l + 64 * i;
@@ -292,6 +294,10 @@ __device__ __forceinline__ void attn_head_body(const HeadAttnArgs &a, char *lds,
       row = row < old_last ? row : old_last;
       vr[i] = *reinterpret_cast<const bf16x8 *>(vbase + (int64_t)row * 128 + (c & 15) * 8);
     }
+  };
+  auto fetch = [&](bf16x8(&kf)[2][4], bf16x8(&vr)[8], int t) {
+    fetch_k(kf, t);
+    fetch_v(vr, t);
   };
   // ---- q rows of this head: QT*16 items, 4 per wave (waves 0 .. 4*QT-1), written swizzled like a K tile.
   // Their loads go out first, the first K/V tile's behind them (vmcnt is in order), the arithmetic after both.
@@ -473,14 +479,26 @@ __device__ __forceinline__ void attn_head_body(const HeadAttnArgs &a, char *lds,
       }
     };
     // the wave's own LDS tile: its ds_write -> ds_read order is program order (lgkmcnt), no barrier
-    for (; tcur < t1; tcur += 2 * NW) {
-      if (tcur + NW < t1) fetch(kB, vB, tcur + NW);
-      put_v(vA);
-      compute(kA, my_v, tcur * 32, S, 32, false);
-      if (tcur + NW >= t1) break;
-      if (tcur + 2 * NW < t1) fetch(kA, vA, tcur + 2 * NW);
-      put_v(vB);
-      compute(kB, my_v, (tcur + NW) * 32, S, 32, false);
+    if (QT == 1) {
+      for (; tcur < t1; tcur += 2 * NW) {
+        if (tcur + NW < t1) fetch(kB, vB, tcur + NW);
+        put_v(vA);
+        compute(kA, my_v, tcur * 32, S, 32, false);
+        if (tcur + NW >= t1) break;
+        if (tcur + 2 * NW < t1) fetch(kA, vA, tcur + 2 * NW);
+        put_v(vB);
+        compute(kB, my_v, (tcur + NW) * 32, S, 32, false);
+      }
+    } else {
+      // two query tiles: 64 accumulator + 32 q registers more, no room for a second K/V tile in flight (hipcc spilled
+      // each V fragment right behind its load: eight serial round trips per tile); K of the next tile is requested
+      // once the current one's QK^T is done with it, V once it sits in LDS
+      for (; tcur < t1; tcur += NW) {
+        put_v(vA);
+        if (tcur + NW < t1) fetch_v(vA, tcur + NW);
+        compute(kA, my_v, tcur * 32, S, 32, false);
+        if (tcur + NW < t1) fetch_k(kA, tcur + NW);
+      }
     }
   }
 
