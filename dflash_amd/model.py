@@ -59,6 +59,18 @@ class DFlashKVCache:
             self.length = max(0, self.length + int(max_length))
 
 
+
+class WideRows:
+    """What draft_block returns for a 17..32-row block on the one-pass path: the final-normed rows of both 16-row
+    tiles as frag16 (a ragged-batch row source, R = 2); draft_tokens runs ONE lm_head pass over them."""
+
+    def __init__(self, src, dyn, tiles: int = 2):
+        self.src, self.dyn, self.tiles = src, dyn, tiles   # dyn: the two tiles' length records [2, 8]
+
+    def __len__(self):
+        return self.tiles
+
+
 class DFlashDraftModel:
     def __init__(self, config, device=None):
         self.config = DFlashConfig.from_any(config)
@@ -81,6 +93,10 @@ class DFlashDraftModel:
         # "head": dfl_attn_head on finished bf16 q/k/v rows (round 2); "fused": round-1 stage on fp32 partials
         self.attn_impl = "head"
         self.fuse_oproj = False    # True: attention + o_proj in one launch (dfl_attn_head_oproj); measured slower
+        # blocks of 17..32 rows: True = ONE pass over the weights through the ragged-batch GEMMs (R = 2), False = the
+        # single-request GEMMs once per 16-row tile (two passes; kept for A/B and as a second implementation for tests)
+        self.wide_one_pass = True
+        self._wide = None
         self.wide_prefill = True   # False: the round-1 context prefill in 16-row groups (kept for A/B timing and tests)
 
     # ------------------------------------------------------------------ weights
@@ -342,6 +358,8 @@ class DFlashDraftModel:
             ops.gemm_resid(w["kv_all"], src["ctx"], c.num_hidden_layers * 2 * c.kv_dim, H, ws["xc"], add_residual=False,
                            dyn=dyn)
         L = w["layers"]
+        if len(tiles) == 2 and self.wide_one_pass and head:
+            return self._draft_block_wide(cache, ws, S, tau, bs, pos0, block_ids, embed, noise, append, cos, sin)
         if noise is not None:  # public forward(): the caller embedded the block itself
             ws["h"][:bs].copy_(noise[:bs])
             ws["ss_emb"][:bs].copy_(noise[:bs].float().pow(2).sum(-1))
@@ -390,6 +408,54 @@ class DFlashDraftModel:
             cache.length = S + tau
         return src["final"][:len(tiles)]
 
+    def _draft_block_wide(self, cache, ws, S, tau, bs, pos0, block_ids, embed, noise, append, cos, sin) -> WideRows:
+        """The block rows of a 17..32-row block in ONE pass over the layer weights: the two 16-row tiles go through the
+        ragged-batch GEMMs (R = 2: fp32 K-part sums of o_proj / down_proj, residual add + RMSNorm in
+        dfl_norm_frag_batch) and ONE attention launch with two query tiles (model/dflash.py:166-190)."""
+        c, w, R = self.config, self.w, 2
+        H, I, eps = c.hidden_size, c.intermediate_size, c.rms_norm_eps
+        nqkv = c.q_dim + 2 * c.kv_dim
+        if self._wide is None:
+            ks, d = ops.batch_ksplit, self.device
+            xn = torch.zeros(2, 16 * H, dtype=BF16, device=d)
+            nmax, kmax = max(c.vocab_size, 2 * I, nqkv), max(H, I, c.q_dim)
+            self._wide = dict(
+                xn=xn, ids=torch.zeros(2, 16, dtype=torch.int64, device=d),
+                part_h=torch.zeros(max(ks(c.q_dim), ks(I)) * 2 * 16 * H, dtype=torch.float32, device=d),
+                gws=torch.zeros(max(ops.lib().dfl_gemm_batch_ws_bytes(n, k) for n, k in ((nmax, H), (H, kmax))),
+                                dtype=torch.uint8, device=d),
+                src=dict(xn=ops.brows_frag(xn), attn=ops.brows_frag(ws["attn_frag"]), act=ops.brows_frag(ws["act_frag"])))
+        ww = self._wide
+        s, gws, part_h, xn = ww["src"], ww["gws"], ww["part_h"], ww["xn"]
+        dyn2 = cache.dyn[:16].view(2, 8)
+        h3, xq3 = ws["h"].view(2, 16, H), ws["xq"].view(2, 16, nqkv)
+        if noise is not None:   # public forward(): the caller embedded the block itself
+            ws["h"][:bs].copy_(noise[:bs])
+        else:
+            ww["ids"].view(-1)[:bs].copy_(block_ids[:bs])
+            ops.embed_rows_batch(embed, ww["ids"], R, h3, H, ws["ss_emb"].view(2, 16), dyn2, ops.DYN_BS)
+        pend = 0   # K of the GEMM whose fp32 sums wait in part_h (added by the next norm launch)
+        for i, lw in enumerate(w["layers"]):
+            ops.norm_frag_batch(h3, R, lw["ln1"], eps, xn, dyn2, ops.DYN_BS, part=part_h if pend else None, N=H, K=pend)
+            ops.gemm_resid_batch(lw["qkv"], s["xn"], R, nqkv, H, xq3, add_residual=False, ws=gws, dyn=dyn2)
+            ops.attn_head(xq=ws["xq"], q_col=0, k_col=c.q_dim, v_col=c.q_dim + c.kv_dim,
+                          xc=ws["xc"] if tau > 0 else None, ck_col=i * 2 * c.kv_dim, cv_col=i * 2 * c.kv_dim + c.kv_dim,
+                          n_q=c.num_attention_heads, n_kv=c.num_key_value_heads, q_norm_w=lw["q_norm"],
+                          k_norm_w=lw["k_norm"], eps=eps, cos_tab=cos, sin_tab=sin, kcache=cache.k[i], vcache=cache.v[i],
+                          scale=c.head_dim ** -0.5, causal=False, S=S, tau=tau, bs=bs, pos0=pos0, ws=ws["head_ws"],
+                          max_splits=self.max_splits, out_frag=ws["attn_frag"], q_tiles=2,
+                          out_tile_stride=ws["attn_frag"].stride(0))
+            ops.gemm_f32_batch(lw["o"], s["attn"], R, H, c.q_dim, part_h, dyn2)
+            ops.norm_frag_batch(h3, R, lw["ln2"], eps, xn, dyn2, ops.DYN_BS, part=part_h, N=H, K=c.q_dim)
+            ops.gemm_silu_mul_batch(lw["gu"], s["xn"], R, I, H, ws["act_frag"], gws, dyn2)
+            ops.gemm_f32_batch(lw["down"], s["act"], R, H, I, part_h, dyn2)
+            pend = I
+        # last down_proj's sums -> h (the rows forward() returns after its own norm), final norm -> frag16
+        ops.norm_frag_batch(h3, R, w["norm"], eps, xn, dyn2, ops.DYN_BS, part=part_h, N=H, K=pend)
+        if append:
+            cache.length = S + tau
+        return WideRows(s["xn"], dyn2)
+
     def draft_tokens(self, hid_frag, lm_head_wp: torch.Tensor, bs: int, block_ids: torch.Tensor,
                      logits: Optional[torch.Tensor] = None, margins: Optional[torch.Tensor] = None) -> None:
         """block_ids[1:bs] <- argmax(lm_head(hidden[1:bs])) (model/dflash.py:238,245,247).
@@ -398,6 +464,15 @@ class DFlashDraftModel:
         logit of block slot j >= 1, the reference's per-position confidence
         (benchmark_candidate_solutions.py:296-302)."""
         c, ws = self.config, self._workspace()
+        if isinstance(hid_frag, WideRows):   # both tiles in one lm_head pass (ragged-batch GEMM, R = 2)
+            if margins is not None:
+                raise NotImplementedError("top-2 margins are computed for blocks of <= 16 rows")
+            ww = self._wide
+            ops.gemm_argmax_batch(lm_head_wp, hid_frag.src, 2, c.vocab_size, c.hidden_size, 0, 16, ww["gws"], ww["ids"], 0,
+                                  hid_frag.dyn, nrows_dyn_word=ops.DYN_BS,
+                                  logits=None if logits is None else logits.view(2, 16, c.vocab_size))
+            block_ids[1:bs].copy_(ww["ids"].view(-1)[1:bs])
+            return
         srcs = hid_frag if isinstance(hid_frag, (list, tuple)) else [hid_frag]
         for t, x in enumerate(srcs):
             row0 = 1 if t == 0 else 0

@@ -60,6 +60,10 @@ class NativeTarget:
         # True: attention + o_proj in one launch (dfl_attn_head_oproj) where its range allows.  Measured SLOWER than the
         # two launches (23.2 vs 20.3 us per layer): off by default, kept for A/B and tests
         self.fuse_oproj = False
+        # blocks of 17..32 rows: True = one pass over the weights through the ragged-batch GEMMs (R = 2), False = the
+        # single-request GEMMs once per 16-row tile (two passes; kept for A/B and as a second implementation for tests)
+        self.wide_one_pass = True
+        self._wide = None
         cfg = hf_model.config
         self.hf = hf_model
         self.model = hf_model.model
@@ -250,6 +254,67 @@ class NativeTarget:
     # ---- the verify forward on the kernels
     @torch.inference_mode()
 
+    def _verify_wide(self, block_ids, start, cache, bs, tap_layers, taps, logits_out, temperature, cos, sin):
+        """Blocks of 17..32 rows in ONE pass over the weights: the two 16-row tiles go through the ragged-batch
+        GEMMs (dfl_*_batch with R = 2: fp32 K-part sums of o_proj / down_proj, residual add + RMSNorm in
+        dfl_norm_frag_batch) as if they were two requests, and through ONE attention launch with two query tiles on the
+        request's single cache.  Same lines as verify(): model/dflash.py:249-257."""
+        ws, H, R = self.ws, self.H, 2
+        if self._wide is None:
+            ks, dev = ops.batch_ksplit, self._dev
+            xn = torch.zeros(2, 16 * H, dtype=BF16, device=dev)
+            nmax, kmax = max(self.V, 2 * self.I, self.nqkv), max(H, self.I, self.q_dim)
+            self._wide = dict(
+                xn=xn, ids=torch.zeros(2, 16, dtype=torch.int64, device=dev),
+                part_h=torch.zeros(max(ks(self.q_dim), ks(self.I)) * 2 * 16 * H, dtype=torch.float32, device=dev),
+                gws=torch.zeros(max(ops.lib().dfl_gemm_batch_ws_bytes(n, k) for n, k in ((nmax, H), (H, kmax))),
+                                dtype=torch.uint8, device=dev),
+                src=dict(xn=ops.brows_frag(xn), attn=ops.brows_frag(ws["attn"]), act=ops.brows_frag(ws["act"])))
+        ww = self._wide
+        s, gws, part_h, xn = ww["src"], ww["gws"], ww["part_h"], ww["xn"]
+        dyn2 = cache.dyn[:16].view(2, 8)
+        h3, xq3 = ws["h"].view(2, 16, H), ws["xq"].view(2, 16, self.nqkv)
+        ww["ids"].view(-1)[:bs].copy_(block_ids[:bs])
+        ops.embed_rows_batch(self.embed, ww["ids"], R, h3, H, ws["ss_emb"].view(2, 16), dyn2, ops.DYN_BS)
+        tap3 = None if taps is None else taps.view(2, 16, taps.shape[1])
+        slots = {}
+        for j, l in enumerate(tap_layers):
+            slots.setdefault(l, []).append(j)
+        pend, ptap, pdup = 0, None, ()   # K and tap view of the down_proj whose sums wait in part_h
+
+        def spread(dups):   # the other slots of a repeated tap id get the same rows (model/utils.py:16-25)
+            for a, b in dups:
+                taps[:, b * H:(b + 1) * H].copy_(taps[:, a * H:(a + 1) * H])
+
+        for i, lw in enumerate(self.layers):
+            ops.norm_frag_batch(h3, R, lw["ln1"], self.eps, xn, dyn2, ops.DYN_BS, part=part_h if pend else None, N=H,
+                                K=pend, tap=ptap)
+            spread(pdup)
+            ops.gemm_resid_batch(lw["qkv"], s["xn"], R, self.nqkv, H, xq3, add_residual=False, ws=gws, dyn=dyn2)
+            ops.attn_head(xq=ws["xq"], q_col=0, k_col=self.q_dim, v_col=self.q_dim + self.kv_dim, n_q=self.n_q,
+                          n_kv=self.n_kv, q_norm_w=lw["q_norm"], k_norm_w=lw["k_norm"], eps=self.eps, cos_tab=cos,
+                          sin_tab=sin, kcache=cache.k[i], vcache=cache.v[i], scale=128 ** -0.5, causal=True, S=start,
+                          tau=0, bs=bs, pos0=start, ws=ws["head_ws"], max_splits=self.max_splits, out_frag=ws["attn"],
+                          q_tiles=2, out_tile_stride=ws["attn"].stride(0))
+            ops.gemm_f32_batch(lw["o"], s["attn"], R, H, self.q_dim, part_h, dyn2)
+            ops.norm_frag_batch(h3, R, lw["ln2"], self.eps, xn, dyn2, ops.DYN_BS, part=part_h, N=H, K=self.q_dim)
+            ops.gemm_silu_mul_batch(lw["gu"], s["xn"], R, self.I, H, ws["act"], gws, dyn2)
+            ops.gemm_f32_batch(lw["down"], s["act"], R, H, self.I, part_h, dyn2)
+            sl = slots.get(i, ())   # a tapped layer's rows exist once the next norm launch has added these sums
+            pend, ptap = self.I, (tap3[:, :, sl[0] * H:(sl[0] + 1) * H] if sl else None)
+            pdup = [(sl[0], b) for b in sl[1:]]
+        ops.norm_frag_batch(h3, R, self.norm, self.eps, xn, dyn2, ops.DYN_BS, part=part_h, N=H, K=pend, tap=ptap)
+        spread(pdup)
+        post = ws["post"]
+        logits = logits_out
+        if temperature >= 1e-5:
+            logits = torch.empty(32, self.V, dtype=BF16, device=self._dev)
+        ops.gemm_argmax_batch(self.lm_wp, s["xn"], R, self.V, H, 0, 16, gws, post.view(2, 16), 0, dyn2,
+                              nrows_dyn_word=ops.DYN_BS, logits=None if logits is None else logits.view(2, 16, self.V))
+        posterior = post[:bs].unsqueeze(0) if temperature < 1e-5 else sample(logits[:bs].unsqueeze(0), temperature)
+        cache.length = start + bs
+        return posterior, taps
+
     def raise_if_failed(self) -> None:
         """fuse_oproj only: a dfl_attn_head_oproj launch whose o_proj workgroups gave up waiting (2 ms) leaves a flag."""
         if self.fuse_oproj and int(self.ws["sync"][ops.ATTN_OPROJ_FAIL_WORD]) != 0:
@@ -295,6 +360,8 @@ class NativeTarget:
                     self._taps[key] = torch.zeros(32, key * H, dtype=BF16, device=self._dev)
                 taps = self._taps[key]
         Ls, src = self.layers, self.src
+        if len(tiles) == 2 and self.wide_one_pass and not self.is_moe and self.attn_impl == "head":
+            return self._verify_wide(block_ids, start, cache, bs, tap_layers, taps, logits_out, temperature, cos, sin)
         hrow = [ws["h"][16 * t:16 * t + 16] for t in range(2)]
         for t, dt in tiles:
             ops.embed_rows(self.embed, block_ids[16 * t:], hrow[t], H, ws["ss_emb"][16 * t:], dt, ops.DYN_BS)

@@ -55,6 +55,11 @@ def test_forward_matches_reference_vectors(tag, cfgf):
             H.assert_close(f"{tag} cache {name} layer {li}", buf[li][:, :n], ref, max_rel=H.KV_MAX_REL)
 
 
+def ops_pack(w):
+    from dflash_amd import ops
+    return ops.pack_weight(w)
+
+
 def _scripted(g, cfg, dtype=BF16):
     base = H.tiny_target(dtype=dtype, device=dev())
     total = len(g["prompt"]) + g["max_new_tokens"]
@@ -601,14 +606,17 @@ def test_wide_blocks_match_reference_ids():
         dflash_generate(m, tgt, torch.tensor([g["prompt"]], device=dev()), cfg.mask_token_id, 8, 33, None, 0.0)
 
 
+@pytest.mark.parametrize("one_pass", [True, False])
 @pytest.mark.parametrize("bs", [17, 24, 32])
-def test_native_verify_wide_block_matches_hf_forward(bs):
-    """The native verify on two 16-row tiles (one launch per tile of every GEMM, both query tiles in the
-    attention launch) against the HF forward: logits of all bs rows, taps, appended K/V."""
+def test_native_verify_wide_block_matches_hf_forward(bs, one_pass):
+    """The native verify on two 16-row tiles against the HF forward: logits of all bs rows, taps, appended K/V.
+    one_pass: both tiles through the ragged-batch GEMMs (one pass over the weights, the default); else one launch
+    per tile of every single-request GEMM.  Both query tiles share the attention launch either way."""
     from transformers import DynamicCache
     from dflash_amd import NativeTarget
     hf = _tiny_hf()
     nt = NativeTarget(hf)
+    nt.wide_one_pass = one_pass
     g = torch.Generator().manual_seed(40 + bs)
     P = 45
     prompt = torch.randint(0, 2000, (1, P), generator=g).to(dev())
@@ -633,6 +641,46 @@ def test_native_verify_wide_block_matches_hf_forward(bs):
         H.assert_close(f"bs {bs} verify K layer {li}", cache.k[li][:, :P + bs], rc.layers[li].keys[0], max_rel=H.KV_MAX_REL)
         H.assert_close(f"bs {bs} verify V layer {li}", cache.v[li][:, :P + bs], rc.layers[li].values[0], max_rel=H.KV_MAX_REL)
     assert cache.get_seq_length() == P + bs
+
+
+@pytest.mark.parametrize("bs,tau", [(24, 9), (32, 16), (17, 0)])
+def test_wide_draft_one_pass_equals_two_passes(bs, tau):
+    """Draft forward of a 17..32-row block: one pass over the weights (ragged-batch GEMMs, R = 2) against the
+    single-request GEMMs run once per 16-row tile — hidden states, appended K/V and the drafted tokens."""
+    cfg = H.tiny_cfg()
+    g = torch.Generator().manual_seed(7 * bs + tau)
+    P = 70
+    th = torch.randn(1, tau, cfg.fc_in, generator=g).to(BF16).to(dev())
+    ne = torch.randn(1, bs, cfg.hidden_size, generator=g).to(BF16).to(dev())
+    ctx0 = torch.randn(P, cfg.fc_in, generator=g).to(BF16).to(dev())
+    lm = (torch.randn(cfg.vocab_size, cfg.hidden_size, generator=g) * 0.05).to(BF16).to(dev())
+    emb = (torch.randn(cfg.vocab_size, cfg.hidden_size, generator=g)).to(BF16).to(dev())
+    ids = torch.randint(0, cfg.vocab_size, (bs,), generator=g).to(dev())
+    outs = {}
+    for one_pass in (True, False):
+        m = make_model(cfg)
+        m.wide_one_pass = one_pass
+        cache = m.new_cache(P + 64)
+        m.prefill_context(cache, ctx0, 0)
+        pos = torch.arange(P, P + tau + bs, device=dev()).unsqueeze(0)
+        hid = m(target_hidden=th, noise_embedding=ne, position_ids=pos, past_key_values=cache, use_cache=True)
+        kv = (cache.k[1][:, :P + tau + bs].clone(), cache.v[1][:, :P + tau + bs].clone())
+        # the loop's form: token ids + embedding table in, drafted ids out
+        cache2 = m.new_cache(P + 64)
+        m.prefill_context(cache2, ctx0, 0)
+        blk = ids.clone()
+        logits = torch.zeros(32, cfg.vocab_size, dtype=BF16, device=dev())
+        with torch.inference_mode():
+            rows = m.draft_block(cache2, th_rows=th[0] if tau else None, tau=tau, bs=bs, pos0=P, block_ids=blk, embed=emb)
+            m.draft_tokens(rows, ops_pack(lm), bs, blk, logits=logits)
+        assert torch.equal(blk[1:], torch.argmax(logits[1:bs], dim=-1)) and blk[0] == ids[0]
+        outs[one_pass] = (hid.clone(), kv, logits[1:bs].clone(), blk.clone())
+    a, b = outs[True], outs[False]
+    H.assert_close(f"wide draft hidden bs {bs}", a[0], b[0])
+    H.assert_close(f"wide draft K bs {bs}", a[1][0], b[1][0], max_rel=H.KV_MAX_REL)
+    H.assert_close(f"wide draft V bs {bs}", a[1][1], b[1][1], max_rel=H.KV_MAX_REL)
+    H.assert_close(f"wide draft logits bs {bs}", a[2], b[2])
+    H.assert_ids_match_where_safe(f"wide draft ids bs {bs}", a[3][1:], b[2].float(), min_safe=0)
 
 
 def test_native_target_wide_blocks_lossless_walk():
