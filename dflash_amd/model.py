@@ -174,7 +174,7 @@ class DFlashDraftModel:
             npart = max(self.ks_fc * 16 * H, self.ks_qkv * 32 * nqkv, self.ks_o * 16 * H, self.ks_down * 16 * H,
                         self.ks_kv * 16 * 2 * c.kv_dim)
             self.max_splits = 32
-            NT = 2  # block rows as up to two 16-row tiles (block sizes 17..32: the weights stream once per tile)
+            NT = 2  # block rows as up to two 16-row tiles (block sizes 17..32)
             self._ws = dict(
                 th_frag=torch.zeros(16 * c.fc_in, dtype=BF16, device=d),
                 ctx_frag=torch.zeros(16 * H, dtype=BF16, device=d),
@@ -332,8 +332,9 @@ class DFlashDraftModel:
         16-row block tile (the lm_head GEMM applies the final RMSNorm; scratch, valid until the next
         call).  K/V of tau+bs rows are written at cache rows S.. ; `append` advances the host length
         by tau (the block rows are dropped again, as crop(start) does at :246).
-        bs <= 32: blocks of 17..32 rows run as two 16-row tiles — every GEMM is launched once per
-        tile (the weights stream twice on such a cycle), the attention takes both query tiles."""
+        bs <= 32: blocks of 17..32 rows run as two 16-row tiles — one pass over the weights through the
+        ragged-batch GEMMs (`_draft_block_wide`, returns a WideRows), or with wide_one_pass = False one launch
+        per tile of every single-request GEMM; the attention takes both query tiles either way."""
         c, ws, w = self.config, self._workspace(), self.w
         if bs < 1 or bs > 32 or tau < 0 or tau > 16:
             raise ValueError(f"bs={bs} / tau={tau}: the kernels take 1..32 block rows and 0..16 context rows")

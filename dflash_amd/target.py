@@ -329,8 +329,9 @@ class NativeTarget:
         K/V of all bs rows are written; the caller crops to what it accepts.
         taps_out: the caller's own [32, len(tap_layers)*H] buffer (a decode session keeps the
         rows until its next draft; sessions interleaved on one target must not share one).
-        logits_out: bf16 [16 * tiles, V].  Blocks of 17..32 rows run as two 16-row tiles: one
-        launch per tile of every GEMM, both query tiles in the attention launch."""
+        logits_out: bf16 [16 * tiles, V].  Blocks of 17..32 rows run as two 16-row tiles: one pass over the
+        weights through the ragged-batch GEMMs (`_verify_wide`; dense targets), or one launch per tile of every
+        single-request GEMM (wide_one_pass = False, MoE targets); both query tiles share the attention launch."""
         bs = block_ids.numel()
         if bs < 1 or bs > 32:
             raise ValueError("verify takes 1..32 block rows")

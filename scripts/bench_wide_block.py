@@ -23,7 +23,8 @@ ids = torch.randint(0, 1000, (1, P + 64), device=dev)
 
 
 def timed(fn, n=12):
-    fn()
+    for _ in range(3):   # one-off work of the first calls (weight packing, code-object loads, lazy workspaces)
+        fn()
     torch.cuda.synchronize()
     t = time.perf_counter()
     for _ in range(n):
