@@ -69,6 +69,7 @@ SIGNATURES = {
     "dfl_moe_down": (_i, [_p, _i64, _p, _i64, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
     "dfl_argmax": (_i, [_p, _i, _i, _i64, _p, _p]),
     "dfl_accept_commit": (_i, [_p, _p, _i, _p, _i64, _p, _p, _i, _p, _p]),
+    "dfl_accept_commit_rearm": (_i, [_p, _p, _i, _p, _i64, _p, _p, _i, _p, _p, _i, _i64, _p]),
     # ---- ragged batch of requests
     "dfl_batch_tiles": (_i, [_i]),
     "dfl_batch_ksplit": (_i, [_i]),

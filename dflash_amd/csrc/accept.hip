@@ -62,9 +62,12 @@ __global__ __launch_bounds__(256) void k_argmax(const T *__restrict__ logits, in
 // Single wavefront.  Lane i compares draft token i+1 with the target's token for
 // the same position; the accepted length is the number of trailing-zero-free ones
 // of the ballot (first mismatch by ffs), no host round trip.
+// next_block (optional): the NEXT cycle's block, re-armed here so that the host need not copy it out of output_ids
+// (model/dflash.py:235: block = output_ids[:, start:start+bs] = the bonus token followed by mask ids) — rearm_n slots.
 __global__ __launch_bounds__(64) void k_accept_commit(const int64_t *block_ids, const int64_t *posterior, int bs,
                                                       int64_t *output_ids, int64_t output_len, int32_t *dyn,
-                                                      const int64_t *stop_ids, int n_stop, int32_t *result) {
+                                                      const int64_t *stop_ids, int n_stop, int32_t *result,
+                                                      int64_t *next_block, int rearm_n, int64_t mask_id) {
   const int i = threadIdx.x;
   const int start = dyn[DFL_DYN_START];
   const bool cmp = i < bs - 1;
@@ -82,6 +85,10 @@ __global__ __launch_bounds__(64) void k_accept_commit(const int64_t *block_ids, 
   if (i <= acc + 1)
     for (int s = 0; s < n_stop; ++s) hit |= (tok == stop_ids[s]);
   const bool any_stop = __ballot(hit) != 0ull;
+  if (next_block && i < rearm_n) {  // every compared id was read before the ballot above: in-place re-arm is safe
+    const int64_t bonus = posterior[acc];
+    next_block[i] = i == 0 ? bonus : mask_id;
+  }
   if (i == 0) {
     const int new_start = start + acc + 1;
     dyn[DFL_DYN_S] = start;         // draft cache keeps rows [0, start): crop(start), :246
@@ -90,11 +97,16 @@ __global__ __launch_bounds__(64) void k_accept_commit(const int64_t *block_ids, 
     dyn[DFL_DYN_START] = new_start; // :261
     dyn[DFL_DYN_STOP] |= any_stop ? 1 : 0;
     dyn[DFL_DYN_CYCLE] += 1;
-    if (result) {
-      result[0] = acc;
-      result[1] = new_start;
-      result[2] = dyn[DFL_DYN_STOP];
-      result[3] = dyn[DFL_DYN_CYCLE];
+    if (result) {  // ONE 16-byte store: the words arrive together in pinned host memory a CPU thread may be polling
+      const int4 r = make_int4(acc, new_start, dyn[DFL_DYN_STOP], dyn[DFL_DYN_CYCLE]);
+      if ((reinterpret_cast<uintptr_t>(result) & 15) == 0) {
+        *reinterpret_cast<int4 *>(result) = r;
+      } else {
+        result[0] = r.x;
+        result[2] = r.z;
+        result[3] = r.w;
+        result[1] = r.y;
+      }
     }
   }
 }
@@ -186,8 +198,21 @@ extern "C" int dfl_accept_commit(const int64_t *block_ids, const int64_t *poster
   DFL_REQUIRE(bs >= 1 && bs <= 63, "dfl_accept_commit: bs=%d outside 1..63", bs);
   DFL_REQUIRE(n_stop == 0 || stop_ids, "dfl_accept_commit: n_stop>0 without stop_ids");
   hipLaunchKernelGGL(k_accept_commit, dim3(1), dim3(64), 0, (hipStream_t)stream, block_ids, posterior, bs, output_ids,
-                     output_len, dyn, stop_ids, n_stop, result);
+                     output_len, dyn, stop_ids, n_stop, result, (int64_t *)nullptr, 0, (int64_t)0);
   DFL_CHECK_LAUNCH("dfl_accept_commit");
+  return DFL_OK;
+}
+
+extern "C" int dfl_accept_commit_rearm(const int64_t *block_ids, const int64_t *posterior, int bs, int64_t *output_ids,
+                                       int64_t output_len, int32_t *dyn, const int64_t *stop_ids, int n_stop,
+                                       int32_t *result, int64_t *next_block, int rearm_n, int64_t mask_id, void *stream) {
+  DFL_REQUIRE(block_ids && posterior && output_ids && dyn && next_block, "dfl_accept_commit_rearm: null pointer");
+  DFL_REQUIRE(bs >= 1 && bs <= 63 && rearm_n >= 1 && rearm_n <= 64, "dfl_accept_commit_rearm: bs=%d rearm_n=%d outside range", bs,
+              rearm_n);
+  DFL_REQUIRE(n_stop == 0 || stop_ids, "dfl_accept_commit_rearm: n_stop>0 without stop_ids");
+  hipLaunchKernelGGL(k_accept_commit, dim3(1), dim3(64), 0, (hipStream_t)stream, block_ids, posterior, bs, output_ids,
+                     output_len, dyn, stop_ids, n_stop, result, next_block, rearm_n, mask_id);
+  DFL_CHECK_LAUNCH("dfl_accept_commit_rearm");
   return DFL_OK;
 }
 

@@ -16,6 +16,7 @@ target's hidden states and roll its cache back.
 """
 from __future__ import annotations
 
+import os
 import time
 from types import SimpleNamespace
 from typing import Callable, Optional
@@ -109,8 +110,14 @@ class DecodeSession:
         self.stop_t = torch.tensor(stop_token_ids, dtype=torch.long, device=dev) if stop_token_ids else None
         # the reference scans the whole buffer, mask slots included (model/dflash.py:265-268)
         self.stop_always = stop_token_ids is not None and mask_token_id in stop_token_ids
-        self.result = torch.zeros(4, dtype=torch.int32, device=dev)
+        # the accept result {acc, new start, stop, cycle}: pinned host memory the kernel writes with one 16-byte store and
+        # this thread polls (no blit kernel, no interrupt-driven wake); DFL_HOST_RESULT=0: a device buffer + .tolist()
+        self.poll_result = os.environ.get("DFL_HOST_RESULT", "1") != "0"
+        self.result = (torch.zeros(4, dtype=torch.int32).pin_memory() if self.poll_result
+                       else torch.zeros(4, dtype=torch.int32, device=dev))
+        self._res_np = self.result.numpy() if self.poll_result else None
         self.block = torch.empty(1, self.max_bs, dtype=torch.long, device=dev)
+        self._armed = False   # True: the accept kernel has written the next cycle's block (bonus token + mask ids)
         self.start = self.n_in
         self.target_hidden = None
         self.hook_calls = 0
@@ -183,7 +190,8 @@ class DecodeSession:
         """One pass of model/dflash.py:235-268 with block size `bs` (>= 1)."""
         start = self.start
         blk = self.block[:, :bs]
-        blk.copy_(self.output_ids[:, start:start + bs])
+        if not self._armed:   # model/dflash.py:235; afterwards dfl_accept_commit_rearm leaves the same ids in self.block
+            blk.copy_(self.output_ids[:, start:start + bs])
         if bs > 1:
             self._mark("draft", 0)
             self._draft(blk, bs, draft_steps)
@@ -208,9 +216,21 @@ class DecodeSession:
             posterior = sample(out.logits, self.temperature)
         # ---- accept scan + commit + bookkeeping on the device (:258-268)
         ops.set_dyn(self.dyn, 0, 0, bs, start)  # start word = pos0 + tau = start
+        if self.poll_result:
+            self._res_np[1] = -1
         ops.accept_commit(blk[0], posterior[0].contiguous(), bs, self.output_ids[0], self.dyn, self.stop_t,
-                          self.result)
-        res = self.result.tolist()  # the cycle's one device->host read (synchronises the stream)
+                          self.result, rearm=(self.block[0], self.max_bs, self.mask_token_id))
+        self._armed = True
+        if self.poll_result:   # the cycle's one device->host hand-over: the kernel's 16-byte store into pinned memory
+            t0 = time.perf_counter()
+            while self._res_np[1] == -1:
+                if time.perf_counter() - t0 > 0.05:   # a long verify: stop burning the core, block on the stream
+                    torch.cuda.current_stream().synchronize()
+                    if self._res_np[1] == -1:
+                        raise RuntimeError("dfl_accept_commit: the result never arrived in host memory")
+            res = self._res_np.tolist()
+        else:
+            res = self.result.tolist()  # device->host copy (synchronises the stream)
         tau = res[0] + 1
         self.start = start + tau
         self.tcache.crop(self.start)

@@ -415,15 +415,29 @@ def argmax(logits: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def accept_commit(block_ids, posterior, bs: int, output_ids, dyn, stop_ids=None, result=None) -> None:
+def accept_commit(block_ids, posterior, bs: int, output_ids, dyn, stop_ids=None, result=None, rearm=None) -> None:
+    """result: int32[4] on the GPU, or PINNED host memory (the kernel stores the four words with one 16-byte store, a
+    CPU thread may poll them).  rearm = (next_block int64 tensor, n, mask_id): the next cycle's block is written by
+    the kernel (dfl_accept_commit_rearm)."""
     n_stop = 0 if stop_ids is None else stop_ids.numel()
+    rp = None
     if result is not None:
-        assert result.numel() >= 4
-    check(lib().dfl_accept_commit(_p(block_ids, I64, "block_ids"), _p(posterior, I64, "posterior"), bs,
-                                  _p(output_ids, I64, "output_ids"), output_ids.numel(), _p(dyn, I32, "dyn"),
-                                  _p(stop_ids, I64, "stop_ids") if n_stop else None, n_stop, _p(result, I32, "result"),
-                                  _stream()),
-          "dfl_accept_commit")
+        assert result.numel() >= 4 and result.dtype == I32
+        if result.is_cuda:
+            rp = _p(result, I32, "result")
+        else:
+            if not result.is_pinned():
+                raise RuntimeError("dflash_amd: a host-side result buffer must be pinned memory")
+            rp = result.data_ptr()
+    common = (_p(block_ids, I64, "block_ids"), _p(posterior, I64, "posterior"), bs, _p(output_ids, I64, "output_ids"),
+              output_ids.numel(), _p(dyn, I32, "dyn"), _p(stop_ids, I64, "stop_ids") if n_stop else None, n_stop, rp)
+    if rearm is not None:
+        nb, n, mask_id = rearm
+        assert nb.numel() >= n
+        check(lib().dfl_accept_commit_rearm(*common, _p(nb, I64, "next_block"), int(n), int(mask_id), _stream()),
+              "dfl_accept_commit_rearm")
+        return
+    check(lib().dfl_accept_commit(*common, _stream()), "dfl_accept_commit")
 
 
 # ---- ragged batch of requests (include/dflash_hip.h, second half) ---------------------------

@@ -323,6 +323,13 @@ int dfl_accept_commit(const int64_t *block_ids, const int64_t *posterior, int bs
                       int64_t output_len, int32_t *dyn, const int64_t *stop_ids, int n_stop, int32_t *result,
                       void *stream);
 
+/* dfl_accept_commit that also RE-ARMS the next cycle's block on the device (model/dflash.py:235: block =
+ * output_ids[:, start:start+bs] = the token just committed at the new start followed by mask ids):
+ * next_block[0] <- posterior[acc], next_block[1 .. rearm_n-1] <- mask_id (next_block may be block_ids itself). */
+int dfl_accept_commit_rearm(const int64_t *block_ids, const int64_t *posterior, int bs, int64_t *output_ids,
+                            int64_t output_len, int32_t *dyn, const int64_t *stop_ids, int n_stop, int32_t *result,
+                            int64_t *next_block, int rearm_n, int64_t mask_id, void *stream);
+
 /* ======================================================================================
  * Ragged batch of requests on one GPU (BASELINE.json configs[2]; SURVEY.md §8e: "within a
  * GPU the requests are a ragged batch for the kernels: shared weight stream, per-request

@@ -139,12 +139,15 @@ def test_batched_draft_and_verify_match_single_kernels():
         res = dec.accept()
         for r, s in enumerate(sess):
             start = s.start
-            out = s.cycle(16)
+            got = {}   # the drafted block (after the cycle s.block already holds the NEXT block, re-armed by the accept)
+            out = s.cycle(16, after_draft=lambda b: got.update(blk=b[0].clone()))
             assert out.tau == res[r][0], (cyc, r)
             # draft ids: random draft weights leave near-ties that the two summation orders may
             # break differently; the block's first token (committed) must agree, most others do
-            assert s.block[0, 0] == blocks[r, 0]
-            assert int((s.block[0] == blocks[r]).sum()) >= 12, (cyc, r, s.block[0].tolist(), blocks[r].tolist())
+            assert got["blk"][0] == blocks[r, 0]
+            assert int((got["blk"] == blocks[r]).sum()) >= 12, (cyc, r, got["blk"].tolist(), blocks[r].tolist())
+            # the re-armed next block: the bonus token, then mask ids (model/dflash.py:235)
+            assert s.block[0, 0] == s.output_ids[0, s.start] and (s.block[0, 1:] == cfg.mask_token_id).all()
             assert torch.equal(s.output_ids[0, :s.start + 1], dec.output_ids[r, :s.start + 1])
             H.assert_close(f"batch vs single taps c{cyc} r{r}", taps[r, :out.tau], s.target_hidden[0])
             for li in (0, cfg.num_hidden_layers - 1):
@@ -381,10 +384,11 @@ def test_full_size_batch_matches_single_request_path():
         res = dec.accept()
         for r, s in enumerate(sess):
             start = s.start
-            out = s.cycle(16)
+            got = {}   # the drafted block (s.block holds the re-armed NEXT block once the cycle is over)
+            out = s.cycle(16, after_draft=lambda b: got.update(blk=b[0].clone()))
             assert out.tau == res[r][0], (cyc, r)
             assert torch.equal(s.output_ids[0, :s.start + 1], dec.output_ids[r, :s.start + 1])
-            agree.append(float((s.block[0] == blocks[r]).float().mean()))
+            agree.append(float((got["blk"] == blocks[r]).float().mean()))
             H.assert_close(f"8B batch vs single taps c{cyc} r{r}", taps[r, :out.tau], s.target_hidden[0])
             for nm, a, b in (("draft K l4", dec.dk[r, 4][:, :start], s.dcache.k[4][:, :start]),
                              ("draft V l0", dec.dv[r, 0][:, :start], s.dcache.v[0][:, :start]),
