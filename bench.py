@@ -134,13 +134,25 @@ def gpu_leg(args, rank, world, dev):
     from dflash_amd.synthetic import greedy_walk
     G = greedy_walk(perm, prompt, need + 2 * bs).to(dev)
 
+    # The scripted overlay, laid out before the timed loop so that it costs ONE small copy per cycle inside it (the
+    # scripted acceptance lengths fix every cycle's start): row c = k agreeing tokens of G, then a token that is NOT
+    # the target's (the draft forward, lm_head and argmax still run in full; their ids are overwritten).
+    rep_rows = torch.zeros(len(plan), bs, dtype=torch.long)
+    Gc, st = G.cpu(), P
+    for c, k in enumerate(plan[:ncyc + 2]):
+        if st + bs + 1 >= Gc.numel():
+            break
+        rep_rows[c, 1:k + 1] = Gc[st + 1:st + k + 1]
+        if k + 1 < bs:
+            rep_rows[c, k + 1] = (Gc[st + k + 1] + 1) % 151000
+        st += k + 1
+    rep_rows = rep_rows.to(dev)
+
     def hook(blk, start, call):
         k = plan[call]
-        if k:
-            blk[0, 1:k + 1] = G[start + 1:start + k + 1]
-        if k + 1 < bs:  # first non-agreeing slot: anything but the target's token
-            wrong = G[start + k + 1]
-            blk[0, k + 1] = torch.where(blk[0, k + 1] == wrong, (wrong + 1) % 151000, blk[0, k + 1])
+        n = min(k + 2, bs)
+        if n > 1:
+            blk[0, 1:n] = rep_rows[call, 1:n]
 
     for rep in range(2):   # rep 0 pays the one-off costs (code-object loads, allocator, HF lazy init): rep 1 is reported
         s = DecodeSession(draft, target, prompt, mask_token_id=mask_id, max_new_tokens=need, max_block_size=bs,
@@ -242,13 +254,23 @@ def batched_leg(args, rank, dev, draft, target, perm, cfg):
     for r, p in enumerate(prompts):
         dec.admit(r, p)
 
+    # scripted overlay rows laid out before the loop: one small copy per request and cycle inside it (single-request leg)
+    reps = []
+    for r in range(R):
+        rr, Gc, st = torch.zeros(len(plans[r]), bs, dtype=torch.long), Gs[r].cpu(), P
+        for c, k in enumerate(plans[r][:ncyc + 2]):
+            if st + bs + 1 >= Gc.numel():
+                break
+            rr[c, 1:k + 1] = Gc[st + 1:st + k + 1]
+            if k + 1 < bs:
+                rr[c, k + 1] = (Gc[st + k + 1] + 1) % 151000
+            st += k + 1
+        reps.append(rr.to(dev))
+
     def hook(r, blk, start, call):
-        k, G = plans[r][call], Gs[r]
-        if k:
-            blk[0, 1:k + 1] = G[start + 1:start + k + 1]
-        if k + 1 < bs:
-            wrong = G[start + k + 1]
-            blk[0, k + 1] = torch.where(blk[0, k + 1] == wrong, (wrong + 1) % 151000, blk[0, k + 1])
+        n = min(plans[r][call] + 2, bs)
+        if n > 1:
+            blk[0, 1:n] = reps[r][call, 1:n]
 
     dec.cycle(hook)
     dec.cycle(hook)                  # setup, as in the single-request leg: cycle 0 and the first steady-state cycle
