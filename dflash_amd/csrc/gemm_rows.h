@@ -28,15 +28,14 @@ __device__ __forceinline__ bf16x8 ld_stream(const bf16x8 *p) { return __builtin_
 // or past K) is outside the descriptor's range: it returns ZERO and costs no memory traffic,
 // so neither the loads nor the MFMAs that consume them need a guard (guards around loads make
 // hipcc wait vmcnt(0) per fragment; zero weights add zero).
-template <int NF>
+template <int NF, int AUX = 2 /* nt: streamed once; 0 for fragments many workgroups re-read from L2 */>
 __device__ __forceinline__ void load_ksteps(bf16x8 (&wr)[NF], const bf16x8 *first, int nf, int l) {
   const __amdgpu_buffer_rsrc_t r =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16x8 *>(first), 0, (nf < 0 ? 0 : nf) * 1024, 0x00020000);
   const int voff = l * 16;
 #pragma unroll
   for (int f = 0; f < NF; ++f)
-    wr[f] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff + (f & 3) * 1024, (f >> 2) * 4096,
-                                                                            2 /* nt: streamed once */));
+    wr[f] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff + (f & 3) * 1024, (f >> 2) * 4096, AUX));
 }
 
 // sum over the 16 lanes of a DPP row, result in each of them

@@ -384,13 +384,15 @@ def moe_route(logits: torch.Tensor, E: int, top_k: int, norm_topk: bool, wt: tor
                               _stream()), "dfl_moe_route")
 
 
-def gemm_silu_mul_experts(wp_gu: torch.Tensor, x, E: int, I: int, K: int, act: torch.Tensor, active: torch.Tensor,
-                          dyn=None) -> None:
-    """wp_gu bf16 [E, 2*I*K] packed per expert; act bf16 [E, 16*I] (frag16 per expert)."""
+def gemm_silu_mul_experts(wp_gu: torch.Tensor, x, E: int, I: int, K: int, act: torch.Tensor, lst: torch.Tensor,
+                          n_active: torch.Tensor, dyn=None) -> None:
+    """wp_gu bf16 [E, 2*I*K] packed per expert; act bf16 [E, 16*I] (frag16 per expert); lst / n_active: the active
+    experts (dfl_moe_route).  Only their outputs are written."""
     assert wp_gu.dim() == 2 and wp_gu.is_contiguous() and act.dim() == 2 and act.is_contiguous()
     check(lib().dfl_gemm_silu_mul_experts(_p(wp_gu, BF16, "wp_gu"), wp_gu.stride(0), _src(x).ref, E, I, K,
-                                          _p(act, BF16, "act"), act.stride(0), _p(active, I32, "active"),
-                                          _p(dyn, I32, "dyn"), _stream()), "dfl_gemm_silu_mul_experts")
+                                          _p(act, BF16, "act"), act.stride(0), _p(lst, I32, "list"),
+                                          _p(n_active, I32, "n_active"), _p(dyn, I32, "dyn"), _stream()),
+          "dfl_gemm_silu_mul_experts")
 
 
 def moe_down(wp_down: torch.Tensor, act: torch.Tensor, wt: torch.Tensor, lst: torch.Tensor, n_active: torch.Tensor, E: int,

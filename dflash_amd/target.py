@@ -243,7 +243,8 @@ class NativeTarget:
                           ws["n_active"], dyn=dt, dyn_word=ops.DYN_BS)
             if self.debug_routing is not None and t == 0:    # tests: the routing weights of every MoE layer
                 self.debug_routing.append((i, ws["wt"][0].clone()))
-            ops.gemm_silu_mul_experts(lw["gu_e"], self.src["xn"][t], E, self.Ie, H, ws["act_e"], ws["active"], dyn=dt)
+            ops.gemm_silu_mul_experts(lw["gu_e"], self.src["xn"][t], E, self.Ie, H, ws["act_e"], ws["elist"], ws["n_active"],
+                                      dyn=dt)
             ops.moe_down(lw["down_e"], ws["act_e"], ws["wt"][t], ws["elist"], ws["n_active"], E, H, self.Ie,
                          self.moe_nsplit, ws["moe_part"])
             tap = taps[16 * t:16 * t + 16, sl[0] * H:(sl[0] + 1) * H] if sl else None
@@ -252,8 +253,6 @@ class NativeTarget:
                           ld2=taps.stride(0) if tap is not None else 0, dyn=dt, dyn_word=ops.DYN_BS)
 
     # ---- the verify forward on the kernels
-    @torch.inference_mode()
-
     def _verify_wide(self, block_ids, start, cache, bs, tap_layers, taps, logits_out, temperature, cos, sin):
         """Blocks of 17..32 rows in ONE pass over the weights: the two 16-row tiles go through the ragged-batch
         GEMMs (dfl_*_batch with R = 2: fp32 K-part sums of o_proj / down_proj, residual add + RMSNorm in
@@ -321,6 +320,7 @@ class NativeTarget:
             self.ws["sync"].zero_()
             raise RuntimeError("dfl_attn_head_oproj: an o_proj workgroup gave up waiting for the attention stage")
 
+    @torch.inference_mode()
     def verify(self, block_ids: torch.Tensor, start: int, cache: TargetKVCache, *, tap_layers: Sequence[int] = (),
                temperature: float = 0.0, logits_out: Optional[torch.Tensor] = None,
                taps_out: Optional[torch.Tensor] = None):

@@ -294,16 +294,18 @@ int dfl_candidate_select(const int64_t *blocks, int64_t blk_stride, const int64_
  *    top_k (<= 8; ties: lower expert first) -> divided by their sum (norm_topk) -> bf16 -> wt bf16 [16][E] (0 = not routed);
  *    active int32 [E]; list = the active experts in ascending order, *n_active their number.  Rows >= dyn[dyn_word] route
  *    nowhere.  E <= 256.
- *  dfl_gemm_silu_mul_experts: dfl_gemm_silu_mul for every active expert in one launch (grid.z = expert): expert e's
- *    packed gate/up weight at wp + e * wp_expert_stride elements, its frag16 output at act_frag + e * act_expert_stride.
+ *  dfl_gemm_silu_mul_experts: dfl_gemm_silu_mul for every ACTIVE expert (list[0 .. *n_active)) in one launch: the
+ *    workgroups share out the (expert, gate/up column pair) items; expert e's packed gate/up weight at wp + e *
+ *    wp_expert_stride elements, its frag16 output at act_frag + e * act_expert_stride — back to back: the strides must
+ *    be exactly 2*I*K and 16*I.
  *  dfl_moe_down: out[c][m][n] = sum over the c-th share of the active experts of wt[m][e] * (act_e[m] . Wd_e[n]) as fp32
  *    (nsplit shares; dfl_norm_pack adds them to the residual stream and rounds once, where the reference rounds every
  *    expert's output and accumulates in bf16: fewer roundings, inside the bf16 tolerance). */
 int dfl_moe_route(const void *logits, int ld, int E, int top_k, int norm_topk, void *wt, int32_t *active, int32_t *list,
                   int32_t *n_active, const int32_t *dyn, int dyn_word, void *stream);
 int dfl_gemm_silu_mul_experts(const void *wp_gateup, int64_t wp_expert_stride, const dfl_rows *x, int E, int I, int K,
-                              void *act_frag, int64_t act_expert_stride, const int32_t *active, const int32_t *dyn,
-                              void *stream);
+                              void *act_frag, int64_t act_expert_stride, const int32_t *list, const int32_t *n_active,
+                              const int32_t *dyn, void *stream);
 int dfl_moe_down(const void *wp_down, int64_t wp_expert_stride, const void *act_frag, int64_t act_expert_stride,
                  const void *wt, const int32_t *list, const int32_t *n_active, int E, int N, int I, int nsplit, float *out,
                  void *stream);

@@ -102,7 +102,7 @@ def test_grouped_expert_gemms_match_torch():
     xf = torch.empty(16 * Hd, dtype=BF16, device=dev())
     ops.pack_rows(x, 16, xf)
     act = torch.full((E, 16 * I), float("nan"), dtype=BF16, device=dev())
-    ops.gemm_silu_mul_experts(gu_p, ops.rows_frag(xf), E, I, Hd, act, active)
+    ops.gemm_silu_mul_experts(gu_p, ops.rows_frag(xf), E, I, Hd, act, lst, n)
     out = torch.zeros(2, 16, Hd, dtype=torch.float32, device=dev())
     ops.moe_down(dn_p, act, wt, lst, n, E, Hd, I, 2, out)
     got = out.sum(0)
