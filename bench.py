@@ -7,14 +7,16 @@
 Workload (BASELINE.json configs[1]): Qwen3-8B-shaped target (36 layers,
 HF `Qwen3ForCausalLM`, PyTorch-ROCm — outside the hot path) + 5-layer DFlash-b16 draft,
 seeded random-init bf16 weights, one request per GPU, 1024 random prompt ids, block 16,
-temperature 0.  A *step* is one decode cycle: draft block forward + fused lm_head/argmax
-(HIP), target verify (PyTorch), posterior argmax + accept/commit (HIP).
+temperature 0.  A *step* is one decode cycle: draft block forward + fused lm_head/argmax,
+target verify (NativeTarget: the same HIP kernels; `--hf-verify` sends it through the HF forward
+instead), posterior argmax + accept/commit.
 
 Random weights never agree (tau == 1), so acceptance is scripted as SURVEY.md §8d
 prescribes: the target's greedy continuation G is known beforehand and, after the
 fully timed draft forward + argmax, the draft tokens are overwritten with
 G[start+1 : start+k] followed by a wrong id, k drawn from a seeded truncated-geometric
-law whose mean tau matches the published 7.3 (the K timed cycles are conditioned on it).
+law whose mean tau matches the published 7.3 (the K timed cycles are conditioned on it; the
+overlay rows are laid out before the timed loop, inside it they cost one 16-id copy per cycle).
 `value` is committed tokens / wall time over all ranks; `raw_tau1_value` is the same cycles
 counted at tau = 1.  Setup before the W warmup steps: prefill, cycle 0 (it carries the one-off
 projection of the prompt's 1024 context rows into the draft cache) and the first steady-state
