@@ -45,6 +45,7 @@ SIGNATURES = {
     "dfl_embed_rows": (_i, [_p, _p, _p, _i, _p, _p, _i, _p]),
     "dfl_argmax_ws_bytes": (_i64, []),
     "dfl_gemm_argmax": (_i, [_p, _r, _i, _i, _i, _i, _p, _i, _p, _p, _i, _p, _p, _p]),
+    "dfl_gemm_argmax_timed": (_i, [_p, _r, _i, _i, _i, _i, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p]),
     "dfl_norm_pack": (_i, [_p, _i, _i64, _i, _i, _p, _p, _p, _p, _p, _i64, _p, _f, _p, _i, _p, _i, _p]),
     "dfl_qknorm_rope_append": (_i, [_p, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _f, _p, _p, _i, _p, _p, _p, _i, _p,
                                     _i, _i, _p]),

@@ -679,9 +679,10 @@ extern "C" int dfl_gemm_silu_mul_experts(const void *wp_gateup, int64_t wp_exper
 
 extern "C" int64_t dfl_argmax_ws_bytes(void) { return 256 * 16 * (int64_t)(2 * sizeof(float) + sizeof(int)); }
 
-extern "C" int dfl_gemm_argmax(const void *wp, const dfl_rows *x, int V, int K, int row0, int nrows,
-                               const int32_t *dyn, int nrows_dyn_word, void *ws, int64_t *out_ids, int out_off,
-                               void *logits, float *margin_out, void *stream) {
+namespace {
+int gemm_argmax_impl(const void *wp, const dfl_rows *x, int V, int K, int row0, int nrows, const int32_t *dyn,
+                     int nrows_dyn_word, void *ws, int64_t *out_ids, int out_off, void *logits, float *margin_out,
+                     hipEvent_t ev0, hipEvent_t ev1, void *stream) {
   DFL_REQUIRE(wp && ws && out_ids, "dfl_gemm_argmax: null pointer");
   DFL_REQUIRE(V > 0 && K > 0 && V % 16 == 0 && K % 32 == 0, "dfl_gemm_argmax: need V%%16==0, K%%32==0 (V=%d K=%d)", V, K);
   DFL_REQUIRE(row0 >= 0 && nrows >= 0 && row0 + nrows <= 16, "dfl_gemm_argmax: rows [%d,%d) outside the 16-row tile", row0,
@@ -705,11 +706,28 @@ extern "C" int dfl_gemm_argmax(const void *wp, const dfl_rows *x, int V, int K, 
   a.logits = (bf16_t *)logits;
   a.N = V;
   const int gx = grid_x_for(a.ntiles);
+  if (ev0) (void)hipEventRecord(ev0, (hipStream_t)stream);
   hipLaunchKernelGGL((k_gemm<1, false, EPI_ARGMAX>), dim3(gx, 1), dim3(1024), 0, (hipStream_t)stream, a);
+  if (ev1) (void)hipEventRecord(ev1, (hipStream_t)stream);
   hipLaunchKernelGGL(k_argmax_finish, dim3(16), dim3(64), 0, (hipStream_t)stream, a.best_val, a.best_idx, a.best2_val, gx,
                      row0, nrows, dyn, nrows_dyn_word, out_ids, out_off, margin_out);
   DFL_CHECK_LAUNCH("dfl_gemm_argmax");
   return DFL_OK;
+}
+}  // namespace
+
+extern "C" int dfl_gemm_argmax(const void *wp, const dfl_rows *x, int V, int K, int row0, int nrows,
+                               const int32_t *dyn, int nrows_dyn_word, void *ws, int64_t *out_ids, int out_off,
+                               void *logits, float *margin_out, void *stream) {
+  return gemm_argmax_impl(wp, x, V, K, row0, nrows, dyn, nrows_dyn_word, ws, out_ids, out_off, logits, margin_out, nullptr,
+                          nullptr, stream);
+}
+
+extern "C" int dfl_gemm_argmax_timed(const void *wp, const dfl_rows *x, int V, int K, int row0, int nrows,
+                                     const int32_t *dyn, int nrows_dyn_word, void *ws, int64_t *out_ids, int out_off,
+                                     void *logits, float *margin_out, void *ev_start, void *ev_end, void *stream) {
+  return gemm_argmax_impl(wp, x, V, K, row0, nrows, dyn, nrows_dyn_word, ws, out_ids, out_off, logits, margin_out,
+                          (hipEvent_t)ev_start, (hipEvent_t)ev_end, stream);
 }
 
 #ifdef DFL_EXPERIMENTAL_MLP

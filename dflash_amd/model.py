@@ -97,6 +97,7 @@ class DFlashDraftModel:
         # single-request GEMMs once per 16-row tile (two passes; kept for A/B and as a second implementation for tests)
         self.wide_one_pass = True
         self._wide = None
+        self.lm_head_events = None  # (start, end) torch.cuda.Event pair around the next lm_head GEMM launch (bench.py)
         self.wide_prefill = True   # False: the round-1 context prefill in 16-row groups (kept for A/B timing and tests)
 
     # ------------------------------------------------------------------ weights
@@ -480,9 +481,10 @@ class DFlashDraftModel:
             nrows = min(bs - 16 * t, 16) - row0
             if nrows <= 0:
                 continue
+            ev = self.lm_head_events if t == 0 else None   # bench.py: the lm_head kernel itself between two events
             ops.gemm_argmax(lm_head_wp, x, c.vocab_size, c.hidden_size, row0, nrows, ws["argmax_ws"], block_ids,
                             16 * t + row0, logits=None if logits is None else logits[16 * t:16 * t + 16],
-                            margins=margins)
+                            margins=margins, events=ev)
 
     # ------------------------------------------------------------------ reference API
     @torch.inference_mode()

@@ -169,15 +169,21 @@ def argmax_ws(device) -> torch.Tensor:
 
 def gemm_argmax(wp, x, V: int, K: int, row0: int, nrows: int, ws, out_ids: torch.Tensor, out_off: int = 0,
                 dyn=None, nrows_dyn_word: int = -1, logits: Optional[torch.Tensor] = None,
-                margins: Optional[torch.Tensor] = None) -> None:
-    """margins: optional fp32 tensor indexed like out_ids: top-1 minus top-2 logit per row."""
+                margins: Optional[torch.Tensor] = None, events=None) -> None:
+    """margins: optional fp32 tensor indexed like out_ids: top-1 minus top-2 logit per row.
+    events: (start, end) torch.cuda.Event pair (enable_timing, already recorded once so that their handles exist),
+    recorded right around the GEMM launch itself (dfl_gemm_argmax_timed)."""
     if logits is not None:
         assert logits.numel() >= 16 * V
     if margins is not None:
         assert margins.numel() >= out_off + nrows
-    check(lib().dfl_gemm_argmax(_p(wp, BF16, "wp"), _src(x).ref, V, K, row0, nrows, _p(dyn, I32, "dyn"),
-                                nrows_dyn_word, _p(ws), _p(out_ids, I64, "out_ids"), out_off,
-                                _p(logits, BF16, "logits"), _p(margins, F32, "margins"), _stream()), "dfl_gemm_argmax")
+    args = (_p(wp, BF16, "wp"), _src(x).ref, V, K, row0, nrows, _p(dyn, I32, "dyn"), nrows_dyn_word, _p(ws),
+            _p(out_ids, I64, "out_ids"), out_off, _p(logits, BF16, "logits"), _p(margins, F32, "margins"))
+    if events is not None:
+        check(lib().dfl_gemm_argmax_timed(*args, events[0].cuda_event, events[1].cuda_event, _stream()),
+              "dfl_gemm_argmax_timed")
+        return
+    check(lib().dfl_gemm_argmax(*args, _stream()), "dfl_gemm_argmax")
 
 
 def gemm_resid(wp, x, N: int, K: int, h_io: torch.Tensor, *, add_residual: bool, ss_out=None, tap=None,

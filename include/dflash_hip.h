@@ -134,6 +134,11 @@ int64_t dfl_argmax_ws_bytes(void);
 int dfl_gemm_argmax(const void *wp, const dfl_rows *x, int V, int K, int row0, int nrows, const int32_t *dyn,
                     int nrows_dyn_word, void *ws, int64_t *out_ids, int out_off, void *logits, float *margin_out,
                     void *stream);
+/* The same, with two hipEvent_t recorded on `stream` right before and right after the GEMM launch (the argmax finish
+ * launch comes behind ev_end): bench.py times the lm_head kernel itself with them (roofline.achieved). */
+int dfl_gemm_argmax_timed(const void *wp, const dfl_rows *x, int V, int K, int row0, int nrows, const int32_t *dyn,
+                          int nrows_dyn_word, void *ws, int64_t *out_ids, int out_off, void *logits, float *margin_out,
+                          void *ev_start, void *ev_end, void *stream);
 
 /* GEMM with the residual epilogue (o_proj / down_proj / fc, model/dflash.py:101,140,144,177):
  *   v = bf16(x W^T);  h_io[m][n] <- add_residual ? bf16(h_io[m][n] + v) : v;
