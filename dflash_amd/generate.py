@@ -215,7 +215,10 @@ class DecodeSession:
             self._mark("target", 1)
             posterior = sample(out.logits, self.temperature)
         # ---- accept scan + commit + bookkeeping on the device (:258-268)
-        ops.set_dyn(self.dyn, 0, 0, bs, start)  # start word = pos0 + tau = start
+        if not (bs > 1 and draft_steps == 1):
+            # (after a cached draft forward the record already holds start = pos0 + tau and cleared stop / cycle words:
+            # draft_block's dfl_set_dyn2 wrote them into this very buffer)
+            ops.set_dyn(self.dyn, 0, 0, bs, start)  # start word = pos0 + tau = start
         if self.poll_result:
             self._res_np[1] = -1
         ops.accept_commit(blk[0], posterior[0].contiguous(), bs, self.output_ids[0], self.dyn, self.stop_t,
