@@ -320,6 +320,45 @@ def test_fused_attention_oproj_launch_is_equivalent():
     H.assert_close("K rows layer 3, one launch vs two", res[True][2], res[False][2], max_rel=H.KV_MAX_REL)
 
 
+def test_accept_result_in_pinned_memory_equals_device_buffer(monkeypatch):
+    """The loop's per-cycle hand-over: the accept kernel's 16-byte store into pinned host memory, polled by the host
+    (default), against a device buffer read back with .tolist() (DFL_HOST_RESULT=0) — same ids, same acceptance
+    lengths; and the block the kernel re-arms for the next cycle is what the reference slices out of output_ids
+    (model/dflash.py:235)."""
+    from dflash_amd import NativeTarget, dflash_generate
+    from dflash_amd.generate import DecodeSession
+    from dflash_amd.synthetic import greedy_walk, impose_greedy_walk
+    cfg = H.tiny_cfg()
+    hf = _tiny_hf()
+    perm = impose_greedy_walk(hf, seed=8)
+    prompt = torch.randint(0, 2000, (1, 29), generator=torch.Generator().manual_seed(12)).to(dev())
+    G = greedy_walk(perm, prompt, 100).to(dev())
+    plan = H.make_plan(64, 16, 5)
+
+    def hook(blk, start, call):
+        k = min(plan[call], blk.shape[1] - 1)
+        blk[0, 1:k + 1] = G[start + 1:start + k + 1]
+        if k + 1 < blk.shape[1]:
+            blk[0, k + 1] = (G[start + k + 1] + 1) % 2000
+
+    runs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("DFL_HOST_RESULT", mode)
+        m = make_model(cfg)
+        r = dflash_generate(m, NativeTarget(hf), prompt, cfg.mask_token_id, 60, 16, None, 0.0, draft_token_hook=hook)
+        assert r.output_ids[0].tolist() == G[:29 + 60].tolist(), mode
+        runs[mode] = r
+    assert runs["1"].acceptance_lengths == runs["0"].acceptance_lengths
+    monkeypatch.setenv("DFL_HOST_RESULT", "1")
+    s = DecodeSession(make_model(cfg), NativeTarget(hf), prompt, mask_token_id=cfg.mask_token_id, max_new_tokens=40,
+                      max_block_size=16, stop_token_ids=None, temperature=0.0, draft_token_hook=hook)
+    assert s.result.is_pinned()
+    s.prefill()
+    for _ in range(3):
+        s.cycle(16)
+        assert torch.equal(s.block[0], s.output_ids[0, s.start:s.start + 16])
+
+
 def test_temperature_path_with_sharp_logits():
     """T = 0.7 (BASELINE config 4's sampling path): softmax + torch.multinomial on the
     posterior, acceptance on the device.  With the scripted target's +-10 logits the
