@@ -276,28 +276,30 @@ __device__ __forceinline__ void attn_head_body(const HeadAttnArgs &a, char *lds,
   bf16x8 kA[2][4], vA[8], kB[2][4], vB[8];
   // all loads of a tile are unconditional with clamped rows (they batch; rows >= S are masked
   // below and never touch memory another workgroup writes in this launch)
-  auto fetch_k = [&](bf16x8(&kf)[2][4], int t) {
+  // (lim = old_last: a real tile; lim = 0: a DUMMY fetch — every lane reads row 0, one or two cache lines per
+  // instruction, already in L1/L2 — issued where the loops below have nothing left to prefetch, see there)
+  auto fetch_k = [&](bf16x8(&kf)[2][4], int t, int lim) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       int row = t * 32 + u * 16 + qi;
-      row = row < old_last ? row : old_last;
+      row = row < lim ? row : lim;
 #pragma unroll
       for (int s = 0; s < 4; ++s)
         kf[u][s] = *reinterpret_cast<const bf16x8 *>(kbase + (int64_t)row * 128 + s * 32 + g * 8);
     }
   };
-  auto fetch_v = [&](bf16x8(&vr)[8], int t) {
+  auto fetch_v = [&](bf16x8(&vr)[8], int t, int lim) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int c = l + 64 * i;
       int row = t * 32 + (c >> 4);
-      row = row < old_last ? row : old_last;
+      row = row < lim ? row : lim;
       vr[i] = *reinterpret_cast<const bf16x8 *>(vbase + (int64_t)row * 128 + (c & 15) * 8);
     }
   };
-  auto fetch = [&](bf16x8(&kf)[2][4], bf16x8(&vr)[8], int t) {
-    fetch_k(kf, t);
-    fetch_v(vr, t);
+  auto fetch = [&](bf16x8(&kf)[2][4], bf16x8(&vr)[8], int t, int lim) {
+    fetch_k(kf, t, lim);
+    fetch_v(vr, t, lim);
   };
   // ---- q rows of this head: QT*16 items, 4 per wave (waves 0 .. 4*QT-1), written swizzled like a K tile.
   // Their loads go out first, the first K/V tile's behind them (vmcnt is in order), the arithmetic after both.
@@ -327,7 +329,7 @@ __device__ __forceinline__ void attn_head_body(const HeadAttnArgs &a, char *lds,
     // the first tile's loads are issued by EVERY wave of an old split, with or without a tile (clamped rows of
     // valid cache memory): under a per-wave branch the compiler loses count of what is in flight and makes the q
     // arithmetic wait for the whole K/V burst instead of for its own four loads
-    fetch(kA, vA, tcur < t1 ? tcur : 0);
+    fetch(kA, vA, tcur < t1 ? tcur : 0, old_last);
     asm volatile("" ::: "memory");
     finish_q();
   } else {
@@ -479,25 +481,37 @@ __device__ __forceinline__ void attn_head_body(const HeadAttnArgs &a, char *lds,
       }
     };
     // the wave's own LDS tile: its ds_write -> ds_read order is program order (lgkmcnt), no barrier
-    if (QT == 1) {
-      for (; tcur < t1; tcur += 2 * NW) {
-        if (tcur + NW < t1) fetch(kB, vB, tcur + NW);
+    // A wave with ONE tile (S ~ 1k: every wave) just computes it.  A wave with several walks them with the next tile
+    // in flight, and there every fetch is UNCONDITIONAL: behind a conditional fetch hipcc cannot count the loads in
+    // flight and waits vmcnt(0) before the next ds_write / MFMA, i.e. for the tile it has just requested — one full
+    // memory round trip per tile (2.9 us per tile at S = 8192, where a wave walks six).  Where nothing is left to
+    // prefetch the fetch degenerates to a dummy (lim = 0).
+    if (tcur + NW >= t1) {
+      if (tcur < t1) {
         put_v(vA);
         compute(kA, my_v, tcur * 32, S, 32, false);
-        if (tcur + NW >= t1) break;
-        if (tcur + 2 * NW < t1) fetch(kA, vA, tcur + 2 * NW);
-        put_v(vB);
-        compute(kB, my_v, (tcur + NW) * 32, S, 32, false);
+      }
+    } else if (QT == 1) {
+      for (; tcur < t1; tcur += 2 * NW) {
+        fetch(kB, vB, tcur + NW, tcur + NW < t1 ? old_last : 0);
+        put_v(vA);
+        compute(kA, my_v, tcur * 32, S, 32, false);
+        fetch(kA, vA, tcur + 2 * NW, tcur + 2 * NW < t1 ? old_last : 0);
+        if (tcur + NW < t1) {
+          put_v(vB);
+          compute(kB, my_v, (tcur + NW) * 32, S, 32, false);
+        }
       }
     } else {
       // two query tiles: 64 accumulator + 32 q registers more, no room for a second K/V tile in flight (hipcc spilled
       // each V fragment right behind its load: eight serial round trips per tile); K of the next tile is requested
       // once the current one's QK^T is done with it, V once it sits in LDS
       for (; tcur < t1; tcur += NW) {
+        const int lim = tcur + NW < t1 ? old_last : 0;
         put_v(vA);
-        if (tcur + NW < t1) fetch_v(vA, tcur + NW);
+        fetch_v(vA, tcur + NW, lim);
         compute(kA, my_v, tcur * 32, S, 32, false);
-        if (tcur + NW < t1) fetch_k(kA, tcur + NW);
+        fetch_k(kA, tcur + NW, lim);
       }
     }
   }
