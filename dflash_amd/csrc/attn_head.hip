@@ -224,16 +224,23 @@ struct HeadLds {
 // beside the o_proj workgroups that wait for it (SIGNAL: the workgroup that writes a head's final output stores it
 // write-through and then counts the head on *done_ctr).  (kvh, by, cand) = blockIdx.x / .y / .z of k_attn_head:
 // cand = candidate of a multi-candidate verify / request of a ragged batch (0 otherwise).
-template <int QT, int NW, bool SIGNAL>
+// HP (with QT = 2): the two 16-row "tiles" are not two query tiles of one head but the same <= 16 rows of TWO query heads
+// of the kv group (head, head + 1): every K/V tile a wave fetches serves both.  Long prefixes (the host switches at
+// ~5k keys): the G heads of a kv group otherwise pull the same K/V through their XCD's L2 G times (S = 8192: 134 MB of
+// L2 reads per launch for 33.5 MB of cache, PMC: HBM fetch 34 MB), and with half the workgroups per split there are
+// twice the splits.
+template <int QT, int NW, bool SIGNAL, bool HP = false>
 __device__ __forceinline__ void attn_head_body(const HeadAttnArgs &a, char *lds, int *s_last_p, const int kvh, const int by,
                                                const int cand, int *done_ctr) {
+  static_assert(!HP || QT == 2, "head pairs use the two-tile register layout");
   using L = HeadLds<QT, NW>;
   int &s_last = *s_last_p;
 
   const int tid = threadIdx.x;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
-  const int hh = by % a.G, split = by / a.G;
-  const int head = kvh * a.G + hh;
+  const int hpg = HP ? a.G >> 1 : a.G;  // workgroups per kv head and split
+  const int hh = by % hpg, split = by / hpg;
+  const int head = kvh * a.G + (HP ? 2 * hh : hh);
   const int ns = a.ns_old + 1;
   const bool is_new = split == a.ns_old;
   int S = a.S, tau = a.tau, bs = a.bs, pos0 = a.pos0;
@@ -304,11 +311,13 @@ __device__ __forceinline__ void attn_head_body(const HeadAttnArgs &a, char *lds,
   // ---- q rows of this head: QT*16 items, 4 per wave (waves 0 .. 4*QT-1), written swizzled like a K tile.
   // Their loads go out first, the first K/V tile's behind them (vmcnt is in order), the arithmetic after both.
   char *q_lds = lds + L::kQ;
-  const int jq = 4 * w + g;  // this 16-lane group's q row (QT = 1: waves 0..3 hold rows, the others a dummy)
+  const int jq = 4 * w + g;  // this 16-lane group's q item (QT = 1: waves 0..3 hold rows, the others a dummy)
+  const int jrow = HP ? jq & 15 : jq;            // its block row ...
+  const int jhead = HP ? head + (jq >> 4) : head;  // ... and query head
   RopeLoads<1> qld;
   {
-    const bf16_t *src[1] = {jq < bs ? xq + (int64_t)jq * a.ldq + a.q_col + head * 128 : nullptr};
-    const int pos[1] = {pos0 + tau + jq};
+    const bf16_t *src[1] = {jrow < bs ? xq + (int64_t)jrow * a.ldq + a.q_col + jhead * 128 : nullptr};
+    const int pos[1] = {pos0 + tau + jrow};
     rope_issue<1>(src, pos, a.q_w, a.cos_tab, a.sin_tab, a.max_pos, xq, l, qld);
   }
   // (compiler fences: without them hipcc hoists the K/V burst above the q loads and sinks the norm-weight load
@@ -320,7 +329,7 @@ __device__ __forceinline__ void attn_head_body(const HeadAttnArgs &a, char *lds,
       bf16x8 ov[1];
       rope_finish<1>(qld, rp, a.q_w != nullptr, a.eps, l, ov);
       const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-      *reinterpret_cast<bf16x8 *>(q_lds + (jq >> 4) * 4096 + k_swz(jq & 15, qi)) = jq < bs ? ov[0] : z;
+      *reinterpret_cast<bf16x8 *>(q_lds + (jq >> 4) * 4096 + k_swz(jq & 15, qi)) = jrow < bs ? ov[0] : z;
     }
   };
   int tcur = t0 + w;
@@ -423,7 +432,7 @@ __device__ __forceinline__ void attn_head_body(const HeadAttnArgs &a, char *lds,
         for (int r = 0; r < 4; ++r) {
           const int key = key0 + u * 16 + 4 * g + r;
           // causal (target verify): query row j sees new row rel <= tau + j; cached rows always
-          const bool vis = key < nvalid && (!new_rows || !a.causal || key <= tau + qt * 16 + qi);
+          const bool vis = key < nvalid && (!new_rows || !a.causal || key <= tau + (HP ? 0 : qt * 16) + qi);
           const float v = vis ? sc[u][r] * a.scale_log2 : -INFINITY;
           sc[u][r] = v;
           mx = fmaxf(mx, v);
@@ -503,8 +512,10 @@ __device__ __forceinline__ void attn_head_body(const HeadAttnArgs &a, char *lds,
         }
       }
     } else {
-      // two query tiles: 64 accumulator + 32 q registers more, no room for a second K/V tile in flight (hipcc spilled
-      // each V fragment right behind its load: eight serial round trips per tile); K of the next tile is requested
+      // two query tiles / a head pair: 64 accumulator + 32 q registers more, no room for a second K/V tile in flight
+      // (a head pair with K double-buffered and its q fragments re-read from LDS sat at 254 VGPRs and ran SLOWER:
+      // 4.98 against 4.68 ms per cycle at S = 8192).  (First form of the two-tile kernel: hipcc spilled
+      // each V fragment right behind its load: eight serial round trips per tile.)  K of the next tile is requested
       // once the current one's QK^T is done with it, V once it sits in LDS
       for (; tcur < t1; tcur += NW) {
         const int lim = tcur + NW < t1 ? old_last : 0;
@@ -571,7 +582,7 @@ __device__ __forceinline__ void attn_head_body(const HeadAttnArgs &a, char *lds,
 #pragma unroll
     for (int j = 0; j < 8; ++j) r[j] = f2bf(v[j] * inv);
     if (SIGNAL && q >= bs) r = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};  // the GEMM behind it takes rows >= bs as zero
-    bf16x8 *dst = &out_frag[qt * a.out_tile_stride + (head * 16 + dg) * 16 + q];
+    bf16x8 *dst = HP ? &out_frag[((head + qt) * 16 + dg) * 16 + q] : &out_frag[qt * a.out_tile_stride + (head * 16 + dg) * 16 + q];
     if (SIGNAL) {  // read by other workgroups of THIS launch: write-through
       const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(dst, 0, 16, 0x00020000);
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r), rd, 0, 0, 16);
@@ -601,8 +612,8 @@ __device__ __forceinline__ void attn_head_body(const HeadAttnArgs &a, char *lds,
   }
 
   // ---- publish the workgroup's partial write-through, drain, ticket; the head's last arriver merges
-  const size_t item_row = (size_t)head * (QT * 16) + qt * 16 + q;
-  const size_t rows_per_split = (size_t)a.n_q * (QT * 16);
+  const size_t item_row = HP ? (size_t)(head + qt) * 16 + q : (size_t)head * (QT * 16) + qt * 16 + q;
+  const size_t rows_per_split = (size_t)a.n_q * (HP ? 16 : QT * 16);
   const __amdgpu_buffer_rsrc_t ro =
       __builtin_amdgcn_make_buffer_rsrc(o_part, 0, (int)(rows_per_split * ns * 128 * sizeof(float)), 0x00020000);
   const __amdgpu_buffer_rsrc_t rm =
@@ -687,6 +698,12 @@ __global__ __launch_bounds__(512) void k_attn_head(HeadAttnArgs a) {
   __shared__ __attribute__((aligned(16))) char lds[HeadLds<QT, 8>::kBytes];
   __shared__ int s_last;
   attn_head_body<QT, 8, false>(a, lds, &s_last, blockIdx.x, blockIdx.y, blockIdx.z, nullptr);
+}
+
+__global__ __launch_bounds__(512) void k_attn_head_pair(HeadAttnArgs a) {  // two query heads per workgroup
+  __shared__ __attribute__((aligned(16))) char lds[HeadLds<2, 8>::kBytes];
+  __shared__ int s_last;
+  attn_head_body<2, 8, false, true>(a, lds, &s_last, blockIdx.x, blockIdx.y, blockIdx.z, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -838,6 +855,10 @@ extern "C" int64_t dfl_attn_head_ws_bytes(int n_q, int max_splits, int q_tiles) 
 }
 
 namespace {
+bool pair_ok_forced(int knob, bool has_tail, int q_tiles, int G, int bs) {
+  return knob == 1 && !has_tail && q_tiles == 1 && G % 2 == 0 && bs <= 16;
+}
+
 // o_proj behind the attention stage in the same launch (dfl_attn_head_oproj)
 struct OprojTail {
   const void *wo;
@@ -894,6 +915,18 @@ int attn_head_launch(const void *xq, int64_t ldq, int q_col, int k_col, int v_co
   int budget = (tail ? knob_wgs4 : knob_wgs * (n_cand > 1 ? 2 : 1)) / (n_q * n_cand) - 1;
   budget = budget < 1 ? 1 : budget;
   ns_old = ns_old > budget ? budget : ns_old;
+  // Head pairs (k_attn_head_pair): when the splits the budget allows would leave a wave more than one tile, two heads
+  // per workgroup halve the K/V pulled through L2 and double the splits.  DFL_ATTN_HEAD_PAIR=0/1 forces it off / on.
+  static const int knob_pair = [] { const char *e = getenv("DFL_ATTN_HEAD_PAIR"); return e ? atoi(e) : -1; }();
+  // Measured on the 8B shapes (cycle, ms): S = 2048 4.28 -> 4.40 (worse), 4096 4.48 -> 4.49, 8192 4.78 -> 4.68: on from ~5k keys.
+  bool pair = !tail && q_tiles == 1 && G % 2 == 0 && bs <= 16 && nt > tiles * ns_old && nt > 160;
+  if (knob_pair >= 0) pair = pair_ok_forced(knob_pair, tail != nullptr, q_tiles, G, bs);
+  if (pair) {
+    int budget2 = knob_wgs * (n_cand > 1 ? 2 : 1) / ((n_q / 2) * n_cand) - 1;
+    budget2 = budget2 < 1 ? 1 : budget2;
+    ns_old = (nt + tiles - 1) / tiles;
+    ns_old = ns_old > budget2 ? budget2 : ns_old;
+  }
   ns_old = ns_old > max_splits - 1 ? max_splits - 1 : ns_old;
   if (nt == 0 && !dyn) ns_old = 0;
   HeadAttnArgs a{};
@@ -941,8 +974,13 @@ int attn_head_launch(const void *xq, int64_t ldq, int q_col, int k_col, int v_co
   a.out_rows = out_rows;
   a.dyn_cand_stride = dyn_cand_stride;
   a.cache_cand_stride = cache_cand_stride;
-  const dim3 grid(n_kv, G * (ns_old + 1), n_cand);
+  const dim3 grid(n_kv, (pair ? G / 2 : G) * (ns_old + 1), n_cand);
   hipStream_t st = (hipStream_t)stream;
+  if (pair) {
+    hipLaunchKernelGGL(k_attn_head_pair, grid, dim3(512), 0, st, a);
+    DFL_CHECK_LAUNCH("dfl_attn_head");
+    return DFL_OK;
+  }
   if (tail) {
     AttnOArgs p{};
     p.at = a;

@@ -462,7 +462,10 @@ def test_attn_fused_equals_three_launch_path(ops, n_q, n_kv, S, tau, bs, causal)
     (4, 2, 0, 3, 16, False, False), (8, 2, 37, 5, 12, False, True), (32, 8, 1024, 7, 16, False, False),
     (32, 8, 1041, 0, 16, True, False), (32, 4, 300, 16, 16, False, False), (4, 4, 70, 2, 9, False, True),
     (8, 2, 3000, 16, 16, True, True), (32, 8, 9001, 11, 16, False, False), (4, 2, 0, 0, 16, True, False),
-    (8, 8, 255, 16, 5, True, False), (32, 8, 31, 1, 1, True, True)])
+    (8, 8, 255, 16, 5, True, False), (32, 8, 31, 1, 1, True, True),
+    # >= ~5k cached keys: two query heads per workgroup share every K/V tile (k_attn_head_pair), causal and not,
+    # lengths as immediates and from the device record, a ragged last tile
+    (8, 2, 6000, 0, 16, True, False), (16, 8, 7777, 9, 7, False, True), (4, 1, 5300, 16, 16, True, True)])
 def test_attn_head_equals_three_launch_path(ops, n_q, n_kv, S, tau, bs, causal, use_dyn):
     """dfl_attn_head (finished bf16 q/k/v rows in, one launch, one query head per workgroup, wave results
     merged in LDS, sc1 partials) against dfl_qknorm_rope_append + dfl_block_attn fed with the SAME Linear
