@@ -217,7 +217,8 @@ int dfl_attn_fused(const float *qkv, int nsplit, int64_t split_stride, int ld, i
  * target verify's stage, :249-255), but q/k/v arrive as FINISHED bf16 Linear outputs — dfl_gemm_resid(add_residual
  * = 0) of the block rows into xq [bs][ldq] (q | k | v column blocks at q_col / k_col / v_col) and, for the draft,
  * of the context rows into xc [tau][ldc] (k, v at ck_col / cv_col; xc may be NULL when tau == 0) — and the grid is
- * (kv head, query heads of the group x key splits): one query head per workgroup, 8 waves over disjoint 32-key
+ * (kv head, query heads of the group x key splits): one query head per workgroup (two, sharing every K/V tile, from
+ * ~5k cached keys), 8 waves over disjoint 32-key
  * tiles with no barrier in the loop, wave results merged in LDS, one 8 KB partial per workgroup published
  * write-through and merged by the head's last arriver (csrc/attn_head.hip).  New rows (tau + bs <= 64, tau <= 32)
  * are appended to the cache at rows S.. by the launch itself.  bs <= 16 * q_tiles, q_tiles in {1, 2}: the second
