@@ -132,16 +132,23 @@ __global__ __launch_bounds__(1024) void k_moe_down(MoeDownArgs a) {
   const int nitems = (p1 > p0 ? p1 - p0 : 0) * cpe;
   f32x4 total = {0.f, 0.f, 0.f, 0.f};
   bf16x8 wA[4], xA[4], wB[4], xB[4];
-  float rA = 0.f, rB = 0.f;
-  auto issue = [&](bf16x8(&wv)[4], bf16x8(&xv)[4], float &wr, int it) {
+  bf16_t rA = 0, rB = 0;  // (kept as loaded: converting at the load would make the wave wait for it there)
+  // Every request in the loop is UNCONDITIONAL — past the wave's last item a dummy (empty descriptors: zeros, no
+  // traffic): behind `if (more) issue` hipcc cannot count the loads in flight and waits vmcnt(0) before the MFMAs of
+  // the current item, i.e. for the item it has just requested.
+  auto issue = [&](bf16x8(&wv)[4], bf16x8(&xv)[4], bf16_t &wr, int it) {
+    const bool live = it < nitems;
+    it = live ? it : nitems - 1;
     const int e = a.list[p0 + it / cpe], ks0 = (it % cpe) * 4;
     int nf = a.KSe - ks0;
-    nf = nf > 4 ? 4 : nf;
-    wr = bf2f(a.wt[(int64_t)(l & 15) * a.E + e]);  // the routing weight of this lane's row; first: loads return in order
+    // (scalar: a clamp compiled to v_med3 puts the buffer descriptors in VGPRs and every load into a waterfall loop)
+    nf = __builtin_amdgcn_readfirstlane(live ? (nf > 4 ? 4 : nf) : 0);
+    wr = a.wt[(int64_t)(l & 15) * a.E + e];  // the routing weight of this lane's row; first: loads return in order
     load_ksteps<4, 0>(xv, a.act + e * a.act_stride + (size_t)ks0 * 64, nf, l);  // re-read by every column tile: L2
     load_ksteps<4>(wv, a.wd + e * a.wd_stride + ((size_t)t * a.KSe + ks0) * 64, nf, l);  // past nf: zero fragments
   };
-  auto consume = [&](const bf16x8(&wv)[4], const bf16x8(&xv)[4], float wr) {
+  auto consume = [&](const bf16x8(&wv)[4], const bf16x8(&xv)[4], bf16_t wraw) {
+    const float wr = bf2f(wraw);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int f = 0; f < 4; ++f) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[f], xv[f], acc, 0, 0, 0);
@@ -149,13 +156,18 @@ __global__ __launch_bounds__(1024) void k_moe_down(MoeDownArgs a) {
     total += acc * wr;
   };
   int it = w;
-  if (it < nitems) issue(wA, xA, rA, it);
-  for (; it < nitems; it += 32) {
-    if (it + 16 < nitems) issue(wB, xB, rB, it + 16);
-    consume(wA, xA, rA);
-    if (it + 16 >= nitems) break;
-    if (it + 32 < nitems) issue(wA, xA, rA, it + 32);
-    consume(wB, xB, rB);
+  if (it < nitems) {
+    issue(wA, xA, rA, it);
+    for (; it < nitems; it += 32) {
+      issue(wB, xB, rB, it + 16);
+      __builtin_amdgcn_sched_barrier(0);  // (or hipcc sinks the requests below the current item's waits and MFMAs)
+      consume(wA, xA, rA);
+      __builtin_amdgcn_sched_barrier(0);
+      issue(wA, xA, rA, it + 32);
+      __builtin_amdgcn_sched_barrier(0);
+      if (it + 16 < nitems) consume(wB, xB, rB);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
   *reinterpret_cast<f32x4 *>(&red[w][l * 4]) = total;
   __syncthreads();
