@@ -21,12 +21,12 @@ from __future__ import annotations
 import copy
 from collections import Counter, namedtuple
 from types import SimpleNamespace
-from typing import Optional, Sequence
+from typing import Sequence
 
 import torch
 
 from . import ops
-from .generate import DecodeSession, _taps, _trim, cuda_time
+from .generate import DecodeSession, _taps, cuda_time
 from .utils import sample
 
 BF16, F32, I32, I64 = torch.bfloat16, torch.float32, torch.int32, torch.int64

@@ -18,7 +18,6 @@ from __future__ import annotations
 
 import argparse
 import atexit
-import os
 import random
 import sys
 import time
