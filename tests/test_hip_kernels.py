@@ -662,6 +662,30 @@ def test_accept_commit_golden(ops):
         assert (d[0], d[1], d[3], d[4]) == (c["start"], c["acc"] + 1, c["start"], c["new_start"])
 
 
+def test_accept_commit_rearm_and_pinned_result_golden(ops):
+    """The reference's accept cases (G3) through dfl_accept_commit_rearm with the result in PINNED host memory: same
+    acceptance, commit and bookkeeping; the block buffer then holds the next cycle's block (the token committed at the
+    new start followed by mask ids, model/dflash.py:235) — re-armed in place, wider than the block just accepted."""
+    MASK = 151669
+    for c in json.load(open(os.path.join(H.GOLDEN, "accept.json"))):
+        out = torch.full((len(c["out"]),), 9999, dtype=torch.long, device=dev())
+        dyn = torch.zeros(8, dtype=torch.int32, device=dev())
+        res = torch.full((4,), -7, dtype=torch.int32).pin_memory()
+        ops.set_dyn(dyn, 0, 0, c["bs"], c["start"])
+        blk = torch.full((32,), 7777, dtype=torch.long, device=dev())
+        blk[:c["bs"]] = torch.tensor(c["block"], device=dev())
+        ops.accept_commit(blk, torch.tensor(c["posterior"], device=dev()), c["bs"], out, dyn, None, res,
+                          rearm=(blk, 32, MASK))
+        torch.cuda.synchronize()
+        assert res.tolist()[:3] == [c["acc"], c["new_start"], 0]
+        assert out.tolist() == c["out"]
+        assert blk.tolist() == [c["posterior"][c["acc"]]] + [MASK] * 31
+        if c["new_start"] < len(c["out"]):
+            assert blk[0] == out[c["new_start"]]
+    with pytest.raises(RuntimeError):      # a host-side result buffer must be pinned
+        ops.accept_commit(blk, blk, 4, out, dyn, None, torch.zeros(4, dtype=torch.int32))
+
+
 def test_accept_commit_stop_flag(ops):
     block = torch.tensor([5, 6, 7, 8], device=dev())
     post = torch.tensor([6, 7, 99, 3], device=dev())   # acc = 2, bonus token 99
