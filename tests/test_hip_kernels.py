@@ -637,6 +637,62 @@ def test_attn_head_oproj_equals_two_launches(ops, n_q, n_kv, H, S, tau, bs, caus
         assert torch.allclose(got_ss, h2.float().pow(2).sum(-1), rtol=1e-4)
 
 
+@pytest.mark.parametrize("S0", [200, 6100])   # 6100: two query heads per workgroup (k_attn_head_pair) in both forms
+def test_attn_head_batch_and_candidates_equal_single_launches(ops, S0):
+    """dfl_attn_head_batch (R requests of different lengths, lengths from their device records, one cache each) and
+    dfl_attn_head_cand (C candidate blocks on ONE cached prefix, new rows to a staging area) against one
+    dfl_attn_head launch per request / candidate: outputs and appended rows bit-identical (same kernel body, the
+    request index only moves the base pointers)."""
+    from dflash_amd.model import _rope_tables
+    n_q, n_kv, R, L = 8, 2, 3, 2
+    g = gen(S0)
+    ld = (n_q + 2 * n_kv) * 128
+    rows = S0 + 200
+    qw = (1 + 0.1 * torch.randn(128, generator=g)).to(BF16).to(dev())
+    kw = (1 + 0.1 * torch.randn(128, generator=g)).to(BF16).to(dev())
+    cos, sin = _rope_tables(128, 1e6, rows + 64, dev())
+    xq = torch.randn(4, 16, ld, generator=g).to(BF16).to(dev())
+    kc = torch.randn(4, L, n_kv, rows, 128, generator=g).to(BF16).to(dev())
+    vc = torch.randn(4, L, n_kv, rows, 128, generator=g).to(BF16).to(dev())
+    lens = [S0, S0 + 77, S0 - 150]
+    bss = [16, 9, 13]
+    common = dict(q_col=0, k_col=n_q * 128, v_col=(n_q + n_kv) * 128, n_q=n_q, n_kv=n_kv, q_norm_w=qw, k_norm_w=kw, eps=1e-6,
+                  cos_tab=cos, sin_tab=sin, scale=128 ** -0.5)
+    # ---- ragged batch
+    dyn = torch.zeros(4, 8, dtype=torch.int32, device=dev())
+    for r in range(R):
+        ops.set_dyn(dyn[r], lens[r], 0, bss[r], lens[r])
+    kb, vb = kc.clone(), vc.clone()
+    outb = torch.zeros(4, 16 * n_q * 128, dtype=BF16, device=dev())
+    ops.attn_head_batch(xq=xq, R=R, kcache=kb, vcache=vb, layer=1, causal=True, dyn=dyn, kv_len_max=max(lens) + 16,
+                        ws=ops.attn_head_batch_ws(4, n_q, 16, dev()), max_splits=16, out_frag=outb, **common)
+    for r in range(R):
+        k1, v1 = kc[r, 1].clone(), vc[r, 1].clone()
+        out1 = torch.zeros(16 * n_q * 128, dtype=BF16, device=dev())
+        ops.attn_head(xq=xq[r], kcache=k1, vcache=v1, causal=True, S=max(lens), tau=0, bs=16, pos0=0, dyn=dyn[r],
+                      ws=ops.attn_head_ws(n_q, 16, 1, dev()), max_splits=16, out_frag=out1, **common)
+        n = lens[r] + bss[r]
+        assert torch.equal(kb[r, 1][:, :n], k1[:, :n]) and torch.equal(vb[r, 1][:, :n], v1[:, :n]), r
+        assert torch.equal(unfrag(outb[r], n_q * 128)[:bss[r]], unfrag(out1, n_q * 128)[:bss[r]]), r
+    assert torch.equal(kb[:, 0], kc[:, 0])            # the other layer's cache is untouched
+    # ---- candidates on one cached prefix
+    C, S, bs = 4, lens[0], 16
+    k_out = torch.zeros(C, n_kv, 16, 128, dtype=BF16, device=dev())
+    v_out = torch.zeros(C, n_kv, 16, 128, dtype=BF16, device=dev())
+    outc = torch.zeros(C, 16 * n_q * 128, dtype=BF16, device=dev())
+    k0, v0 = kc[0, 0].clone(), vc[0, 0].clone()
+    ops.attn_head_cand(xq=xq, kcache=k0, vcache=v0, S=S, bs=bs, ws=ops.attn_head_batch_ws(C, n_q, 16, dev()), max_splits=16,
+                       out_frag=outc, k_out=k_out, v_out=v_out, **common)
+    assert torch.equal(k0, kc[0, 0]) and torch.equal(v0, vc[0, 0])      # the shared cache is read-only here
+    for c in range(C):
+        k1, v1 = kc[0, 0].clone(), vc[0, 0].clone()
+        out1 = torch.zeros(16 * n_q * 128, dtype=BF16, device=dev())
+        ops.attn_head(xq=xq[c], kcache=k1, vcache=v1, causal=True, S=S, tau=0, bs=bs, pos0=S,
+                      ws=ops.attn_head_ws(n_q, 16, 1, dev()), max_splits=16, out_frag=out1, **common)
+        assert torch.equal(k_out[c], k1[:, S:S + 16]) and torch.equal(v_out[c], v1[:, S:S + 16]), c
+        assert torch.equal(outc[c], out1), c
+
+
 # ------------------------------------------------------------------ integer side, golden
 def test_argmax_golden(ops):
     z = np.load(os.path.join(H.GOLDEN, "argmax.npz"))
