@@ -67,6 +67,7 @@ SIGNATURES = {
     "dfl_candidate_select": (_i, [_p, _i64, _p, _i64, _p, _i, _i, _p, _i64, _p, _p, _i, _p, _p]),
     "dfl_moe_route": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p]),
     "dfl_gemm_silu_mul_experts": (_i, [_p, _i64, _r, _i, _i, _i, _p, _i64, _p, _p, _p, _p]),
+    "dfl_moe_gate_up": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _p, _i, _p]),
     "dfl_moe_down": (_i, [_p, _i64, _p, _i64, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
     "dfl_argmax": (_i, [_p, _i, _i, _i64, _p, _p]),
     "dfl_accept_commit": (_i, [_p, _p, _i, _p, _i64, _p, _p, _i, _p, _p]),

@@ -181,7 +181,111 @@ __global__ __launch_bounds__(1024) void k_moe_down(MoeDownArgs a) {
   }
 }
 
+// Gate/up projection + SiLU of every ACTIVE expert for K <= 2048 (30B-A3B: K = 2048, I = 768): at this K a 16-column
+// tile is only 64 KB, so the skinny GEMM's per-tile LDS meeting of its 16 waves (gemm_skinny.hip) weighs twice what
+// it does at K = 4096.  Here an item is a PAIR (gate tile p, up tile p) of an active expert: every wave holds its 4
+// k-steps of both tiles, the 16 waves meet ONCE per pair, and the finishing threads have gate and up sums side by
+// side for the SiLU epilogue (tf:models/qwen3_moe/modeling_qwen3_moe.py Qwen3MoeExperts.forward; rounding points
+// as in dfl_gemm_silu_mul).  One workgroup per CU walks its share of the (expert, pair) items, next item in flight.
+struct MoeGuArgs {
+  const bf16x8 *wp;      // experts' packed gate/up weights, back to back: [E][2*npp tiles][KS][64]
+  const bf16x8 *xfrag;   // frag16 of the 16 normalised rows [KS][64]
+  const int32_t *list, *n_active, *dyn;
+  int valid_word;
+  int KS, npp;           // K / 32 (<= 64), I / 16
+  bf16_t *act;           // [E][16 * I] frag16 per expert
+};
+
+__global__ __launch_bounds__(1024) void k_moe_gate_up(MoeGuArgs a) {
+  __shared__ float red[2][16][2][256];
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
+  int nfw = a.KS - 4 * w;
+  nfw = __builtin_amdgcn_readfirstlane(nfw < 0 ? 0 : (nfw > 4 ? 4 : nfw));
+  const int nitems = a.n_active[0] * a.npp;
+  const int64_t tile = (int64_t)a.KS * 64, expert = 2 * a.npp * tile;   // bf16x8 units
+  bf16x8 gA[4], uA[4], gB[4], uB[4], xr[4];
+  // (every request unconditional, a dummy past the end: see k_moe_down)
+  auto issue = [&](bf16x8(&g)[4], bf16x8(&u)[4], int it) {
+    const bool live = it < nitems;
+    it = live ? it : nitems - 1;
+    const int e = a.list[it / a.npp], p = it % a.npp;
+    const bf16x8 *base = a.wp + e * expert + 2 * p * tile + 4 * w * 64;
+    const int nf = __builtin_amdgcn_readfirstlane(live ? nfw : 0);
+    load_ksteps<4>(g, base, nf, l);
+    load_ksteps<4>(u, base + tile, nf, l);
+  };
+  int it = blockIdx.x;
+  if (it >= nitems) return;
+  load_ksteps<4, 0>(xr, a.xfrag + 4 * w * 64, nfw, l);   // activations first: a wave's loads return in issue order
+  issue(gA, uA, it);
+  const int nv = (a.dyn && a.valid_word >= 0) ? a.dyn[a.valid_word] : 16;
+  if ((l & 15) >= nv) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f) xr[f] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+  }
+  int pos = 0;
+  auto consume = [&](const bf16x8(&g)[4], const bf16x8(&u)[4], int itc) {
+    f32x4 ag = {0.f, 0.f, 0.f, 0.f}, au = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int f = 0; f < 4; ++f) ag = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g[f], xr[f], ag, 0, 0, 0);
+#pragma unroll
+    for (int f = 0; f < 4; ++f) au = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u[f], xr[f], au, 0, 0, 0);
+    const int buf = pos & 1;
+    ++pos;
+    *reinterpret_cast<f32x4 *>(&red[buf][w][0][l * 4]) = ag;
+    *reinterpret_cast<f32x4 *>(&red[buf][w][1][l * 4]) = au;
+    __syncthreads();
+    if (tid < 256) {  // D layout of the MFMA as in gemm_skinny.hip: thread (row m, column nl) of the pair
+      const int m = tid >> 4, nl = tid & 15;
+      const int idx = 4 * (m + 16 * (nl >> 2)) + (nl & 3);
+      float sg = 0.f, su = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < 16; ++ww) {
+        sg += red[buf][ww][0][idx];
+        su += red[buf][ww][1][idx];
+      }
+      const float gb = rbf(sg), ub = rbf(su);   // the Linears' bf16 outputs
+      const float act = rbf(gb / (1.f + __expf(-gb)));
+      const int e = a.list[itc / a.npp], n = (itc % a.npp) * 16 + nl;
+      a.act[(int64_t)e * (16 * 16 * a.npp) + ((size_t)(n >> 3) * 16 + m) * 8 + (n & 7)] = f2bf(act * ub);
+    }
+  };
+  const int G = gridDim.x;
+  for (; it < nitems; it += 2 * G) {
+    issue(gB, uB, it + G);
+    __builtin_amdgcn_sched_barrier(0);
+    consume(gA, uA, it);
+    __builtin_amdgcn_sched_barrier(0);
+    issue(gA, uA, it + 2 * G);
+    __builtin_amdgcn_sched_barrier(0);
+    if (it + G < nitems) consume(gB, uB, it + G);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 }  // namespace
+
+extern "C" int dfl_moe_gate_up(const void *wp_gateup, const void *x_frag, int E, int I, int K, void *act_frag,
+                               const int32_t *list, const int32_t *n_active, const int32_t *dyn, int valid_word,
+                               void *stream) {
+  DFL_REQUIRE(wp_gateup && x_frag && act_frag && list && n_active, "dfl_moe_gate_up: null pointer");
+  DFL_REQUIRE(E >= 1 && E <= 1024 && I > 0 && I % 16 == 0 && K > 0 && K % 32 == 0 && K <= 2048,
+              "dfl_moe_gate_up: E=%d I=%d K=%d outside range (K <= 2048; larger K: dfl_gemm_silu_mul_experts)", E, I, K);
+  MoeGuArgs a{};
+  a.wp = (const bf16x8 *)wp_gateup;
+  a.xfrag = (const bf16x8 *)x_frag;
+  a.list = list;
+  a.n_active = n_active;
+  a.dyn = dyn;
+  a.valid_word = valid_word;
+  a.KS = K / 32;
+  a.npp = I / 16;
+  a.act = (bf16_t *)act_frag;
+  hipLaunchKernelGGL(k_moe_gate_up, dim3(256), dim3(1024), 0, (hipStream_t)stream, a);
+  DFL_CHECK_LAUNCH("dfl_moe_gate_up");
+  return DFL_OK;
+}
 
 extern "C" int dfl_moe_route(const void *logits, int ld, int E, int top_k, int norm_topk, void *wt, int32_t *active,
                              int32_t *list, int32_t *n_active, const int32_t *dyn, int dyn_word, void *stream) {

@@ -401,6 +401,16 @@ def gemm_silu_mul_experts(wp_gu: torch.Tensor, x, E: int, I: int, K: int, act: t
           "dfl_gemm_silu_mul_experts")
 
 
+def moe_gate_up(wp_gu: torch.Tensor, x_frag: torch.Tensor, E: int, I: int, K: int, act: torch.Tensor, lst: torch.Tensor,
+                n_active: torch.Tensor, dyn=None, valid_word: int = -1) -> None:
+    """gemm_silu_mul_experts for K <= 2048 from frag16 rows: one LDS meeting per (gate, up) tile pair."""
+    assert wp_gu.dim() == 2 and wp_gu.is_contiguous() and wp_gu.shape[1] == 2 * I * K
+    assert act.dim() == 2 and act.is_contiguous() and act.shape[1] == 16 * I and x_frag.numel() >= 16 * K
+    check(lib().dfl_moe_gate_up(_p(wp_gu, BF16, "wp_gu"), _p(x_frag, BF16, "x_frag"), E, I, K, _p(act, BF16, "act"),
+                                _p(lst, I32, "list"), _p(n_active, I32, "n_active"), _p(dyn, I32, "dyn"), valid_word,
+                                _stream()), "dfl_moe_gate_up")
+
+
 def moe_down(wp_down: torch.Tensor, act: torch.Tensor, wt: torch.Tensor, lst: torch.Tensor, n_active: torch.Tensor, E: int,
              N: int, I: int, nsplit: int, out: torch.Tensor) -> None:
     """wp_down bf16 [E, N*I] packed per expert; out fp32 [nsplit, 16, N]."""

@@ -64,6 +64,7 @@ class NativeTarget:
         # single-request GEMMs once per 16-row tile (two passes; kept for A/B and as a second implementation for tests)
         self.wide_one_pass = True
         self._wide = None
+        self.moe_pair_kernel = True   # MoE gate/up at K <= 2048 through dfl_moe_gate_up (False: the general kernel)
         cfg = hf_model.config
         self.hf = hf_model
         self.model = hf_model.model
@@ -243,8 +244,12 @@ class NativeTarget:
                           ws["n_active"], dyn=dt, dyn_word=ops.DYN_BS)
             if self.debug_routing is not None and t == 0:    # tests: the routing weights of every MoE layer
                 self.debug_routing.append((i, ws["wt"][0].clone()))
-            ops.gemm_silu_mul_experts(lw["gu_e"], self.src["xn"][t], E, self.Ie, H, ws["act_e"], ws["elist"], ws["n_active"],
-                                      dyn=dt)
+            if H <= 2048 and self.moe_pair_kernel:   # one LDS meeting per (gate, up) tile pair: 64 KB tiles at K = 2048
+                ops.moe_gate_up(lw["gu_e"], ws["xn"][t], E, self.Ie, H, ws["act_e"], ws["elist"], ws["n_active"], dyn=dt,
+                                valid_word=ops.DYN_BS)
+            else:
+                ops.gemm_silu_mul_experts(lw["gu_e"], self.src["xn"][t], E, self.Ie, H, ws["act_e"], ws["elist"],
+                                          ws["n_active"], dyn=dt)
             ops.moe_down(lw["down_e"], ws["act_e"], ws["wt"][t], ws["elist"], ws["n_active"], E, H, self.Ie,
                          self.moe_nsplit, ws["moe_part"])
             tap = taps[16 * t:16 * t + 16, sl[0] * H:(sl[0] + 1) * H] if sl else None

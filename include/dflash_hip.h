@@ -312,6 +312,12 @@ int dfl_moe_route(const void *logits, int ld, int E, int top_k, int norm_topk, v
 int dfl_gemm_silu_mul_experts(const void *wp_gateup, int64_t wp_expert_stride, const dfl_rows *x, int E, int I, int K,
                               void *act_frag, int64_t act_expert_stride, const int32_t *list, const int32_t *n_active,
                               const int32_t *dyn, void *stream);
+/* dfl_gemm_silu_mul_experts for K <= 2048 and frag16 rows (x_frag: [K/32][64] fragments): an item is the (gate, up)
+ * tile PAIR of an active expert, the 16 waves of a workgroup meet once per pair (at K = 2048 a tile is 64 KB and the
+ * per-tile meeting of the general kernel weighs twice what it does at K = 4096).  Same results, same layouts; rows
+ * >= dyn[valid_word] count as zero (valid_word < 0 or dyn NULL: all 16). */
+int dfl_moe_gate_up(const void *wp_gateup, const void *x_frag, int E, int I, int K, void *act_frag, const int32_t *list,
+                    const int32_t *n_active, const int32_t *dyn, int valid_word, void *stream);
 int dfl_moe_down(const void *wp_down, int64_t wp_expert_stride, const void *act_frag, int64_t act_expert_stride,
                  const void *wt, const int32_t *list, const int32_t *n_active, int E, int N, int I, int nsplit, float *out,
                  void *stream);

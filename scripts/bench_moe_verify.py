@@ -40,6 +40,7 @@ with torch.no_grad():
     for layer in hf.model.layers:
         layer.mlp.gate.weight.mul_(gain)
 nt = NativeTarget(hf)
+nt.moe_pair_kernel = os.environ.get("DFL_MOE_PAIR", "1") != "0"   # A/B: dfl_moe_gate_up vs the general expert GEMM
 g = torch.Generator().manual_seed(1)
 prompt = torch.randint(0, 151000, (1, P), generator=g).to(dev)
 block = torch.randint(0, 151000, (1, 16), generator=g).to(dev)

@@ -77,7 +77,8 @@ def test_moe_route_matches_torch(E, top_k, norm):
     assert k == int(act_ref.sum()) and lst[:k].cpu().tolist() == act_ref.nonzero()[:, 0].tolist()
 
 
-def test_grouped_expert_gemms_match_torch():
+@pytest.mark.parametrize("pair_kernel", [False, True])
+def test_grouped_expert_gemms_match_torch(pair_kernel):
     """dfl_gemm_silu_mul_experts + dfl_moe_down against the HF experts loop in fp32 (Qwen3MoeExperts.forward): only the
     active experts' outputs are computed, the routing-weighted sum over experts comes out as K-part sums."""
     from dflash_amd import ops
@@ -102,7 +103,10 @@ def test_grouped_expert_gemms_match_torch():
     xf = torch.empty(16 * Hd, dtype=BF16, device=dev())
     ops.pack_rows(x, 16, xf)
     act = torch.full((E, 16 * I), float("nan"), dtype=BF16, device=dev())
-    ops.gemm_silu_mul_experts(gu_p, ops.rows_frag(xf), E, I, Hd, act, lst, n)
+    if pair_kernel:   # K <= 2048: one LDS meeting per (gate, up) tile pair
+        ops.moe_gate_up(gu_p, xf, E, I, Hd, act, lst, n)
+    else:
+        ops.gemm_silu_mul_experts(gu_p, ops.rows_frag(xf), E, I, Hd, act, lst, n)
     out = torch.zeros(2, 16, Hd, dtype=torch.float32, device=dev())
     ops.moe_down(dn_p, act, wt, lst, n, E, Hd, I, 2, out)
     got = out.sum(0)
