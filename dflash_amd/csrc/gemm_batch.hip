@@ -115,7 +115,10 @@ __global__ __launch_bounds__(512) void k_gemm_b(GemmBArgs a) {
   // the MT = 4 kernels sat at 256 VGPRs and hipcc spilled the eighth fragment of a weight buffer
   // right after loading it: `s_waitcnt vmcnt(0); scratch_store` in the main loop, which
   // serialises the whole prefetch ring.
-  auto load_item = [&](bf16x8(&wr)[FR], int t) { load_ksteps<FR>(wr, a.wp + ((size_t)t * a.KS + ks0) * 64, nf0, l); };
+  // (live = false: a dummy request — empty descriptor, zeros, no traffic — see the main loop)
+  auto load_item = [&](bf16x8(&wr)[FR], int t, bool live = true) {
+    load_ksteps<FR>(wr, a.wp + ((size_t)t * a.KS + ks0) * 64, live ? nf0 : 0, l);
+  };
 
   // ---- prologue: the first two weight items leave for HBM, then this wave's K slice of every
   // request's tile (it stays in registers for the launch).  Unlike the single-request kernel the
@@ -236,15 +239,23 @@ __global__ __launch_bounds__(512) void k_gemm_b(GemmBArgs a) {
     }
   };
 
-  // three rotating weight buffers: while one item is in the MFMA, the next two are in flight
+  // three rotating weight buffers: while one item is in the MFMA, the next two are in flight.  Every request is
+  // UNCONDITIONAL (a dummy past the last item) and pinned in front of the MFMAs: behind `if (more) load_item` hipcc
+  // cannot count the loads in flight at the join and made the CURRENT item's MFMAs wait vmcnt(0) — for the item just
+  // requested — so that only one item (64 KB per CU with 8 waves) was ever in flight.
   for (int j = 0; j < nseq; j += 3) {
-    if (j + 2 < nseq) load_item(wC, tile_of(j + 2));
+    load_item(wC, tile_of(j + 2 < nseq ? j + 2 : j), j + 2 < nseq);
+    __builtin_amdgcn_sched_barrier(0);
     process(wA, tile_of(j), j);
     if (j + 1 >= nseq) break;
-    if (j + 3 < nseq) load_item(wA, tile_of(j + 3));
+    __builtin_amdgcn_sched_barrier(0);
+    load_item(wA, tile_of(j + 3 < nseq ? j + 3 : j), j + 3 < nseq);
+    __builtin_amdgcn_sched_barrier(0);
     process(wB, tile_of(j + 1), j + 1);
     if (j + 2 >= nseq) break;
-    if (j + 4 < nseq) load_item(wB, tile_of(j + 4));
+    __builtin_amdgcn_sched_barrier(0);
+    load_item(wB, tile_of(j + 4 < nseq ? j + 4 : j), j + 4 < nseq);
+    __builtin_amdgcn_sched_barrier(0);
     process(wC, tile_of(j + 2), j + 2);
   }
 
