@@ -117,6 +117,7 @@ class DecodeSession:
                        else torch.zeros(4, dtype=torch.int32, device=dev))
         self._res_np = self.result.numpy() if self.poll_result else None
         self.block = torch.empty(1, self.max_bs, dtype=torch.long, device=dev)
+        self._dyn_bs = None   # block size for which the draft cache's length record is already armed (see _draft)
         self._armed = False   # True: the accept kernel has written the next cycle's block (bonus token + mask ids)
         self.start = self.n_in
         self.target_hidden = None
@@ -154,12 +155,17 @@ class DecodeSession:
         ctx = self.target_hidden[0]
         if draft_steps == 1:
             S = self.dcache.get_seq_length()
+            head_rows = max(0, ctx.shape[0] - 16)
             if ctx.shape[0] > 16:  # cycle 0: the prompt's context rows, 16 at a time
                 head = ctx.shape[0] - 16
                 m.prefill_context(self.dcache, ctx[:head], S)
                 ctx, S = ctx[head:], S + head
+            # steady state: the accept kernel of the previous cycle wrote S, tau, pos0 and start of THIS forward into
+            # the draft cache's record (dfl_accept_commit); only a changed block size or a context head needs new words
+            ready = self._dyn_bs == bs and head_rows == 0
             hid = m.draft_block(self.dcache, th_rows=ctx, tau=ctx.shape[0], bs=bs, pos0=S, block_ids=blk[0],
-                                embed=self.embed_w)
+                                embed=self.embed_w, dyn_ready=ready)
+            self._dyn_bs = None   # until the accept of this cycle has re-armed the record
             self._mark("lm_head", 0)
             _draft_ids(m, hid, self.lm_wp, bs, blk, self.draft_temperature, self.draft_logits)
             self._mark("lm_head", 1)
@@ -224,6 +230,9 @@ class DecodeSession:
         ops.accept_commit(blk[0], posterior[0].contiguous(), bs, self.output_ids[0], self.dyn, self.stop_t,
                           self.result, rearm=(self.block[0], self.max_bs, self.mask_token_id))
         self._armed = True
+        # the record now holds the next draft forward's S / tau / pos0 / start — if that cycle was a cached draft cycle
+        # on this record (bs > 1, one draft step) and keeps the block size
+        self._dyn_bs = bs if (bs > 1 and draft_steps == 1 and self.use_draft) else None
         if self.poll_result:   # the cycle's one device->host hand-over: the kernel's 16-byte store into pinned memory
             t0 = time.perf_counter()
             while self._res_np[1] == -1:

@@ -326,7 +326,7 @@ class DFlashDraftModel:
 
     def draft_block(self, cache: DFlashKVCache, *, th_rows: Optional[torch.Tensor], tau: int, bs: int, pos0: int,
                     block_ids: Optional[torch.Tensor] = None, embed: Optional[torch.Tensor] = None,
-                    noise: Optional[torch.Tensor] = None, append: bool = True) -> list:
+                    noise: Optional[torch.Tensor] = None, append: bool = True, dyn_ready: bool = False) -> list:
         """One draft forward over the block (model/dflash.py:166-190 for ctx <= 16 rows).
         Context rows `th_rows` [tau, fc_in] and the block (token ids + embedding table,
         or a ready `noise` [bs, H]) -> the row sources of the final-normed hidden states, one per
@@ -349,7 +349,10 @@ class DFlashDraftModel:
         nqkv = c.q_dim + 2 * c.kv_dim
         cos, sin = self._rope_tab(pos0 + tau + bs + 64)
         src = self._src
-        ops.set_dyn2(cache.dyn, S, tau, bs, pos0)
+        if not (dyn_ready and bs <= 16):
+            # (dyn_ready: the caller's last dfl_accept_commit on this record left exactly these words — S, tau, pos0,
+            # start — and the block size has not changed: the decode loop's steady state)
+            ops.set_dyn2(cache.dyn, S, tau, bs, pos0)
         dyn = cache.dyn[:8]
         tiles = [(t, cache.dyn[8 * t:8 * t + 8]) for t in range((bs + 15) // 16)]
         if tau > 0:

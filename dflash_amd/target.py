@@ -348,7 +348,11 @@ class NativeTarget:
         if self.lm_wp is None:
             self.lm_wp = ops.pack_weight(self.lm_head.weight.detach().to(BF16).contiguous())
         cos, sin = self._rope_tab(start + bs + 64)
-        ops.set_dyn2(cache.dyn, start, 0, bs, start)
+        # the verify's kernels read only the tiles' valid-row counts from the record (the attention takes immediates):
+        # it is rewritten when the block size changes, not every cycle
+        if getattr(cache, "_dyn_bs", None) != bs:
+            ops.set_dyn2(cache.dyn, start, 0, bs, start)
+            cache._dyn_bs = bs
         dyn = cache.dyn[:8]
         tiles = [(t, cache.dyn[8 * t:8 * t + 8]) for t in range((bs + 15) // 16)]
         taps = None
