@@ -502,13 +502,21 @@ def main():
         return selftest_cpu(args, rank, world, use_pg)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    # DFL_BENCH_SHARE_GPU=1: REHEARSAL of the N-rank control flow on a one-GPU box — every rank on cuda:0, rendezvous and
+    # timing scalars over gloo (RCCL refuses two ranks on one device).  Its numbers mean nothing and the line says so.
+    rehearsal = os.environ.get("DFL_BENCH_SHARE_GPU") == "1"
+    if rehearsal:
+        local = 0
     if local >= torch.cuda.device_count():
         raise SystemExit(f"bench.py: rank {rank} wants cuda:{local} but only {torch.cuda.device_count()} GPUs are visible")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     if use_pg:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl", device_id=dev)  # RCCL; timing scalars only
+        if rehearsal:
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=dev)  # RCCL; timing scalars only
         world = torch.distributed.get_world_size()                    # n_gpus = the RCCL world actually seen
 
     res = gpu_leg(args, rank, world, dev)
@@ -534,6 +542,8 @@ def main():
             "lossless_fraction": res["lossless_fraction"], "roofline": res["roofline"], "hot_path": res["hot_path"],
             "ttft_side": res.get("ttft_side"), "cpu_baseline": cpu,
         }
+        if rehearsal:
+            line["rehearsal"] = "DFL_BENCH_SHARE_GPU=1: all ranks shared cuda:0 over gloo — control flow only, not a measurement"
         print(json.dumps(line), flush=True)
     if use_pg:
         torch.distributed.destroy_process_group()

@@ -75,6 +75,8 @@ def reduce_timing(seconds: float, units: float, device=None):
     """(max seconds over ranks, total units): the bench's whole-job throughput inputs."""
     if not dist.is_initialized():
         return seconds, units
+    if dist.get_backend() == "gloo":
+        device = None   # host tensors (CPU tests, one-GPU rehearsal)
     t = torch.tensor([seconds, units], dtype=torch.float64, device=device)
     mx, sm = t.clone(), t.clone()
     dist.all_reduce(mx, op=dist.ReduceOp.MAX)
