@@ -722,6 +722,31 @@ def test_wide_draft_one_pass_equals_two_passes(bs, tau):
     H.assert_ids_match_where_safe(f"wide draft ids bs {bs}", a[3][1:], b[2].float(), min_safe=0)
 
 
+@pytest.mark.parametrize("one_pass", [True, False])
+def test_native_verify_wide_block_temperature_path(one_pass):
+    """T = 0.7 on a 24-row block (the materialised-logits branch of the wide verify, softmax + multinomial on 24 rows
+    of device logits): with the large-margin synthetic target the draw is its argmax, so the posterior equals the
+    T = 0 posterior — which is the closed-form greedy walk."""
+    from dflash_amd import NativeTarget
+    from dflash_amd.synthetic import greedy_walk, impose_greedy_walk
+    hf = _tiny_hf()
+    perm = impose_greedy_walk(hf, seed=21)
+    P, bs = 40, 24
+    prompt = torch.randint(0, 2000, (1, P), generator=torch.Generator().manual_seed(5)).to(dev())
+    G = greedy_walk(perm, prompt, bs + 8).to(dev())
+    nt = NativeTarget(hf)
+    nt.wide_one_pass = one_pass
+    posts = []
+    for T in (0.0, 0.7):
+        cache = nt.new_cache(128)
+        nt.prefill(prompt, cache)
+        torch.manual_seed(3)
+        post, _ = nt.verify(G[P:P + bs].contiguous(), P, cache, temperature=T)
+        posts.append(post[0].clone())
+    assert torch.equal(posts[0], G[P + 1:P + bs + 1])          # next-token ids of the walk
+    assert torch.equal(posts[1], posts[0])
+
+
 def test_native_target_wide_blocks_lossless_walk():
     """bs = 24 and a {12, 20, 24} schedule end to end on the NATIVE verify: the committed ids are the target's
     closed-form greedy walk, with scripted acceptance lengths up to 24."""
