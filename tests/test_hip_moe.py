@@ -204,3 +204,22 @@ def test_native_moe_target_end_to_end_lossless_walk():
                                 max_new_tokens=n_new, stop_token_ids=None, temperature=0.0, scheduler=sched,
                                 draft_token_hook=hook)
     assert rp.output_ids[0].tolist() == G[:30 + n_new].tolist()
+    # blocks of 17..32 rows on the MoE target (two 16-row tiles through the per-tile MoE path), fixed and scheduled
+    plan24 = H.make_plan(64, 24, 19)
+
+    def hook24(blk, start, call):
+        k = min(plan24[call], blk.shape[1] - 1)
+        blk[0, 1:k + 1] = G[start + 1:start + k + 1]
+        if k + 1 < blk.shape[1]:
+            blk[0, k + 1] = (G[start + k + 1] + 1) % 2000
+
+    rw = dflash_generate(m, nt, prompt, cfg.mask_token_id, n_new, 24, None, 0.0, draft_token_hook=hook24)
+    assert rw.output_ids[0].tolist() == G[:30 + n_new].tolist() and max(rw.acceptance_lengths) > 16
+    sched2 = EWMAPerformanceScheduler(candidates=[12, 20, 24], scheduler_mode="ewma", warmup_cycles=3, ewma_alpha=0.25,
+                                      switch_margin=0.03, required_streak=2, cooldown_cycles=2, probe_interval=5,
+                                      low_accept_threshold=0.2, low_accept_streak=3, adl_rho=0.3, adl_delta=1.0,
+                                      adl_k_min=12, adl_k_max=24, adl_neighborhood=4)
+    rq = dflash_generate_policy(model=m, target=nt, input_ids=prompt, mask_token_id=cfg.mask_token_id,
+                                max_new_tokens=n_new, stop_token_ids=None, temperature=0.0, scheduler=sched2,
+                                draft_token_hook=hook24)
+    assert rq.output_ids[0].tolist() == G[:30 + n_new].tolist() and max(rq.used_block_sizes) > 16
