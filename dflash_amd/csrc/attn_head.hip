@@ -906,13 +906,15 @@ int attn_head_launch(const void *xq, int64_t ldq, int q_col, int k_col, int v_co
   // scripts/dbg_attn_head_stamps.py; the defaults are the measured choice)
   static const int knob_tiles = [] { const char *e = getenv("DFL_ATTN_HEAD_TILES"); return e ? atoi(e) : 8; }();
   static const int knob_wgs = [] { const char *e = getenv("DFL_ATTN_HEAD_WGS"); return e ? atoi(e) : 224; }();
+  // (several blocks per launch — requests of a ragged batch, candidates: ONE round of workgroups, 256; with 448 the
+  // second half-round of a 4-request launch was a tail: 6.10 -> 5.99 ms per 4-request cycle)
+  static const int knob_wgsm = [] { const char *e = getenv("DFL_ATTN_HEAD_WGS_MULTI"); return e ? atoi(e) : 256; }();
   static const int knob_wgs4 = [] { const char *e = getenv("DFL_ATTN_OPROJ_WGS"); return e ? atoi(e) : 256; }();
   static const int knob_tiles4 = [] { const char *e = getenv("DFL_ATTN_OPROJ_TILES"); return e ? atoi(e) : 4; }();
   // (with the o_proj tail: 4-wave workgroups, two per CU; 256 attention + H/16 o_proj workgroups fill the 512 slots)
   const int tiles = tail ? (knob_tiles4 < 1 ? 1 : knob_tiles4) : (knob_tiles < 1 ? 1 : knob_tiles);
   int ns_old = (nt + tiles - 1) / tiles;
-  // (several blocks per launch: up to two rounds of workgroups, or every block would be left with one split)
-  int budget = (tail ? knob_wgs4 : knob_wgs * (n_cand > 1 ? 2 : 1)) / (n_q * n_cand) - 1;
+  int budget = (tail ? knob_wgs4 : (n_cand > 1 ? knob_wgsm : knob_wgs)) / (n_q * n_cand) - 1;
   budget = budget < 1 ? 1 : budget;
   ns_old = ns_old > budget ? budget : ns_old;
   // Head pairs (k_attn_head_pair): when the splits the budget allows would leave a wave more than one tile, two heads
@@ -922,7 +924,7 @@ int attn_head_launch(const void *xq, int64_t ldq, int q_col, int k_col, int v_co
   bool pair = !tail && q_tiles == 1 && G % 2 == 0 && bs <= 16 && nt > tiles * ns_old && nt > 160;
   if (knob_pair >= 0) pair = pair_ok_forced(knob_pair, tail != nullptr, q_tiles, G, bs);
   if (pair) {
-    int budget2 = knob_wgs * (n_cand > 1 ? 2 : 1) / ((n_q / 2) * n_cand) - 1;
+    int budget2 = (n_cand > 1 ? knob_wgsm : knob_wgs) / ((n_q / 2) * n_cand) - 1;
     budget2 = budget2 < 1 ? 1 : budget2;
     ns_old = (nt + tiles - 1) / tiles;
     ns_old = ns_old > budget2 ? budget2 : ns_old;
