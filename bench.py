@@ -181,6 +181,13 @@ def gpu_leg(args, rank, world, dev):
     for a, b in lm_ev:
         a.record()
         b.record()
+    # the same around ONE gate/up GEMM launch of the target verify per timed cycle (layer = cycle index mod layers): the
+    # kernel with the largest share of the cycle (36 + 5 launches; rocprof: 34 % of the GPU time)
+    gu_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for a, b in gu_ev:
+        a.record()
+        b.record()
+    native = not args.hf_verify
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -189,6 +196,8 @@ def gpu_leg(args, rank, world, dev):
     for i in range(args.steps):
         s.events = {}
         draft.lm_head_events = lm_ev[i]
+        if native:
+            target.gu_events = (i % args.target_layers, gu_ev[i][0], gu_ev[i][1])
         r = s.cycle(bs)
         ev_all.append(s.events)
         tokens += r.tau
@@ -198,12 +207,15 @@ def gpu_leg(args, rank, world, dev):
     dt = time.perf_counter() - t0
     s.events = None
     draft.lm_head_events = None
+    if native:
+        target.gu_events = None
 
     def avg_ms(key):
         return sum(e[key][0].elapsed_time(e[key][1]) for e in ev_all) / len(ev_all)
 
     draft_ms, target_ms = avg_ms("draft"), avg_ms("target")
     lm_ms = sum(a.elapsed_time(b) for a, b in lm_ev) / len(lm_ev)
+    gu_ms = sum(a.elapsed_time(b) for a, b in gu_ev) / len(gu_ev) if native else None
     # committed ids must be the target's own greedy continuation (losslessness)
     n_ok = int((s.output_ids[0, P:s.start] == G[P:s.start]).sum())
     lossless = n_ok / max(1, s.start - P)
@@ -212,33 +224,44 @@ def gpu_leg(args, rank, world, dev):
     dt_max, tok_sum = D.reduce_timing(dt, float(tokens), device=dev)
     _, cyc_sum = D.reduce_timing(dt, float(args.steps), device=dev)
     # PMC passes cannot run inside the timed bench (rocprofv3 --pmc serialises and slows the run): `traffic` is the
-    # committed per-launch HBM byte count of this very kernel — accepted only while the hash of the kernel's sources
-    # stored beside it still matches (scripts/pmc_lm_head_json.py); a changed kernel reports null until re-profiled
-    traffic, traffic_note = None, "no PMC summary for the current kernel sources"
+    # committed per-launch HBM byte count of these very kernels — accepted only while the hash of the kernels' sources
+    # stored beside it still matches (scripts/pmc_kernels_json.py); a changed kernel reports null until re-profiled
+    traffic, traffic_note = {}, "no PMC summary for the current kernel sources"
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     try:
-        from pmc_lm_head_json import source_hash
+        from pmc_kernels_json import source_hash
         for fn in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
-            if fn.endswith("_pmc_lm_head.json"):
+            if fn.endswith("_pmc_kernels.json"):
                 rec = json.load(open(os.path.join(ROOT, "profiles", fn)))
                 if rec.get("kernel_source_sha256_16") == source_hash():
-                    traffic = rec.get("hbm_bytes_per_launch")
+                    traffic = {k: v.get("hbm_bytes_per_launch") for k, v in rec.get("kernels", {}).items()}
                     traffic_note = f"profiles/{fn} (kernel sources unchanged since)"
                     break
     except Exception as e:   # never let bookkeeping break the measurement
         traffic_note = f"PMC summary not read: {type(e).__name__}"
+    GATE_UP_BYTES = 2 * 12288 * 4096 * 2   # Qwen3-8B: gate and up, [12288][4096] bf16 each
+    ev_note = ("achieved/avg_ms from HIP events recorded on the launch stream right before and right after the GEMM launch, "
+               "every timed cycle; traffic = 2*FETCH_SIZE+WRITE_SIZE bytes per launch: " + traffic_note)
+    lm_entry = {"kernel": "k_gemm<1,false,EPI_ARGMAX> (lm_head GEMM + fused argmax; 2 launches per cycle)", "bound": "hbm",
+                "achieved": LM_HEAD_BYTES / (lm_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                "frac": LM_HEAD_BYTES / (lm_ms * 1e-3) / 1e9 / 8000.0, "traffic": traffic.get("lm_head"),
+                "bytes_per_launch": LM_HEAD_BYTES, "avg_ms": lm_ms, "note": ev_note}
+    if gu_ms:
+        # the roofline object names the kernel with the largest share of the timed cycle: the gate/up GEMM
+        # with the fused SiLU*up epilogue, one launch per layer of target and draft; the lm_head GEMM rides beside it
+        roofline = {"kernel": "k_gemm<1,false,EPI_SILU> (gate/up GEMM + SiLU*up epilogue; 41 launches per cycle, the largest "
+                              "share of the cycle)", "bound": "hbm",
+                    "achieved": GATE_UP_BYTES / (gu_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                    "frac": GATE_UP_BYTES / (gu_ms * 1e-3) / 1e9 / 8000.0, "traffic": traffic.get("gate_up"),
+                    "bytes_per_launch": GATE_UP_BYTES, "avg_ms": gu_ms, "note": ev_note, "also": [lm_entry]}
+    else:
+        roofline = lm_entry
     kv_bytes = 20480 * (P + 16)
     hot_bytes = DRAFT_WEIGHT_BYTES + LM_HEAD_BYTES + kv_bytes
     return dict(
         value=tok_sum / dt_max, ms_per_step=1000.0 * dt_max / args.steps, mean_tau=tok_sum / cyc_sum,
         raw_tau1_value=cyc_sum / dt_max, lossless_fraction=lossless,
-        roofline={"kernel": "k_gemm<1,8,EPI_ARGMAX> (lm_head GEMM + fused argmax)", "bound": "hbm",
-                  "achieved": LM_HEAD_BYTES / (lm_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                  "frac": LM_HEAD_BYTES / (lm_ms * 1e-3) / 1e9 / 8000.0, "traffic": traffic,
-                  "bytes_per_launch": LM_HEAD_BYTES, "avg_ms": lm_ms,
-                  "note": "achieved/avg_ms from HIP events recorded on the launch stream right before and right after "
-                          "the GEMM launch (dfl_gemm_argmax_timed), every timed cycle; traffic = 2*FETCH_SIZE+WRITE_SIZE "
-                          "bytes per launch: " + traffic_note},
+        roofline=roofline,
         hot_path={"draft_plus_lm_head_ms_per_cycle": draft_ms, "target_verify_ms_per_cycle": target_ms,
                   "algorithmic_bytes_per_cycle": hot_bytes,
                   "achieved_GBps": hot_bytes / (draft_ms * 1e-3) / 1e9,
@@ -451,7 +474,8 @@ def selftest_cpu(args, rank, world, use_pg):
         dist.barrier()
     dt, units = D.reduce_timing(0.001 * (rank + 1), float(args.steps))
     if rank == 0:
-        print(json.dumps({"metric": "accepted_tokens_per_sec", "value": None, "unit": "tokens/s", "n_gpus": world,
+        print(json.dumps({"metric": "accepted_tokens_per_sec", "value": None, "value_per_gpu": None, "unit": "tokens/s",
+                          "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "selftest": "cpu launcher plumbing, no kernels",
                           "cycles_all_ranks": units, "config": {"parallelism": f"dp{world}",
                                                                 "requests": world * args.requests_per_gpu}}),
@@ -529,7 +553,8 @@ def main():
                    "sample": f"failed: {type(e).__name__}: {e}"}
     if rank == 0:
         line = {
-            "metric": "accepted_tokens_per_sec", "value": res["value"], "unit": "tokens/s", "n_gpus": world,
+            "metric": "accepted_tokens_per_sec", "value": res["value"], "value_per_gpu": res["value"] / world,
+            "unit": "tokens/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "Qwen3-8B-shaped target (" + ("HF/PyTorch-ROCm verify" if args.hf_verify else

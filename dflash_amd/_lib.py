@@ -8,7 +8,8 @@ import os
 import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first, so the kernels share its HIP runtime)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libdflash_hip.so")
+# DFL_LIB_PATH: another build of the SAME library (a diagnostic -D build, an older revision for a same-box A/B)
+LIB_PATH = os.environ.get("DFL_LIB_PATH") or os.path.join(HERE, "lib", "libdflash_hip.so")
 
 _p, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 

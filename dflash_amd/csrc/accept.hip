@@ -97,16 +97,15 @@ __global__ __launch_bounds__(64) void k_accept_commit(const int64_t *block_ids, 
     dyn[DFL_DYN_START] = new_start; // :261
     dyn[DFL_DYN_STOP] |= any_stop ? 1 : 0;
     dyn[DFL_DYN_CYCLE] += 1;
-    if (result) {  // ONE 16-byte store: the words arrive together in pinned host memory a CPU thread may be polling
-      const int4 r = make_int4(acc, new_start, dyn[DFL_DYN_STOP], dyn[DFL_DYN_CYCLE]);
-      if ((reinterpret_cast<uintptr_t>(result) & 15) == 0) {
-        *reinterpret_cast<int4 *>(result) = r;
-      } else {
-        result[0] = r.x;
-        result[2] = r.z;
-        result[3] = r.w;
-        result[1] = r.y;
-      }
+    if (result) {
+      // Hand-over a CPU thread may be polling (pinned host memory): the payload words first, then — behind a
+      // system-scope release, so that no store can overtake them — the cycle counter as the LAST word.  The host
+      // polls word 3 and reads words 0..2 only after it has changed (generate.py); no reliance on a 16-byte store
+      // arriving whole.
+      result[0] = acc;
+      result[1] = new_start;
+      result[2] = dyn[DFL_DYN_STOP];
+      __hip_atomic_store(&result[3], dyn[DFL_DYN_CYCLE], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }

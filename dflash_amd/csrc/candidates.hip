@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void k_topk_rows(const bf16_t *__restrict__ lo
       s = s * __expf(m - f) + 1.f;
       m = f;
     } else {
-      s += __expf(f - m);
+      s += (f == -INFINITY) ? 0.f : __expf(f - m);  // a masked (-inf) entry adds nothing; -inf - -inf would be NaN
     }
     if (better(f, i, v[7], id[7])) {
       v[7] = f;

@@ -5,7 +5,7 @@
 
 namespace {
 
-enum { EPI_F32 = 0, EPI_SILU = 1, EPI_ARGMAX = 2, EPI_RESID = 3 };
+enum { EPI_F32 = 0, EPI_SILU = 1, EPI_ARGMAX = 2, EPI_RESID = 3, EPI_SILU_E = 4 /* SILU over a list of active experts */ };
 
 struct RowSrc {
   const bf16x8 *frag;  // mode 0: frag16 [KS][64]
@@ -28,11 +28,13 @@ __device__ __forceinline__ bf16x8 ld_stream(const bf16x8 *p) { return __builtin_
 // or past K) is outside the descriptor's range: it returns ZERO and costs no memory traffic,
 // so neither the loads nor the MFMAs that consume them need a guard (guards around loads make
 // hipcc wait vmcnt(0) per fragment; zero weights add zero).
+// `half` (0 / 1; -1 = the whole tile): only the lanes of columns 8*half .. 8*half+7 of the 16-column tile load (lane l
+// holds column l & 15); the others get an offset past the descriptor, i.e. zeros and no traffic — branch-free.
 template <int NF, int AUX = 2 /* nt: streamed once; 0 for fragments many workgroups re-read from L2 */>
-__device__ __forceinline__ void load_ksteps(bf16x8 (&wr)[NF], const bf16x8 *first, int nf, int l) {
+__device__ __forceinline__ void load_ksteps(bf16x8 (&wr)[NF], const bf16x8 *first, int nf, int l, int half = -1) {
   const __amdgpu_buffer_rsrc_t r =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16x8 *>(first), 0, (nf < 0 ? 0 : nf) * 1024, 0x00020000);
-  const int voff = l * 16;
+  const int voff = (half < 0 || ((l >> 3) & 1) == half) ? l * 16 : 0x40000000;
 #pragma unroll
   for (int f = 0; f < NF; ++f)
     wr[f] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff + (f & 3) * 1024, (f >> 2) * 4096, AUX));
@@ -105,6 +107,32 @@ __device__ __forceinline__ void finish_x(const RowSrc &s, const bool (&take)[NF]
   }
 }
 
+// finish_x with the RMSNorm weight read from LDS (nwl[c] = elements 8c .. 8c+7, staged once per workgroup by the
+// caller, K <= 4096): no second 32-VGPR fragment array is alive while the activation loads are in flight.
+template <int NF>
+__device__ __forceinline__ void finish_xl(const RowSrc &s, const int (&ks)[NF], const bool (&take)[NF], int l, int nv,
+                                          float rstd, const bf16x8 (&raw)[NF], const bf16x8 *nwl, bf16x8 (&x)[NF]) {
+  const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (s.mode == 0) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) x[f] = take[f] ? raw[f] : z;
+    return;
+  }
+  const int m = l & 15, kq = l >> 4;
+  const bool norm = s.mode == 2;  // Qwen3RMSNorm: weight * bf16(x * rstd), tf:modeling_qwen3.py:59-64
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    const bf16x8 r = raw[f];
+    bf16x8 o = r;
+    if (norm) {
+      const bf16x8 wq = nwl[(ks[f] * 4 + kq) & 511];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(wq[j]) * rbf(bf2f(r[j]) * rstd));
+    }
+    x[f] = (take[f] && m < nv) ? o : z;
+  }
+}
+
 template <int NF, bool NORM = true>
 __device__ __forceinline__ void build_x(const RowSrc &s, const int (&ks)[NF], const bool (&take)[NF], int l, int nv,
                                         float rstd, bf16x8 (&x)[NF]) {
@@ -145,6 +173,10 @@ inline bool fill_src(RowSrc &d, const dfl_rows *s, int K, const char *who) {
   const bool ok = (s->mode == 0 && s->frag) || (s->mode == 1 && s->rows && s->ld >= K && s->ld % 8 == 0) ||
                   (s->mode == 2 && s->rows && s->ss && s->nss >= 1 && s->norm_w && s->ld >= K && s->ld % 8 == 0);
   if (!ok) dfl_set_error("%s: bad row source (mode %d)", who, s->mode);
+  if (ok && s->mode == 2 && K > 4096) {  // the norm weight is staged in 8 KB of LDS; the in-kernel rstd covers one K pass
+    dfl_set_error("%s: a normalised row source needs K <= 4096 (K=%d)", who, K);
+    return false;
+  }
   return ok;
 }
 

@@ -26,13 +26,18 @@
 namespace {
 
 struct GemmArgs {
+  // what the first weight request needs comes first: one s_load of the head of the kernel-argument block
   const bf16x8 *wp;  // packed weights [ntiles][KS][64]
-  RowSrc src[2];
-  const int32_t *dyn;
   int KS;      // K / 32
   int ntiles;  // N / 16
   int nfr;     // k-steps per wave per chunk (<= FR)
   int nch;     // K chunks walked inside the workgroup (1 unless CHUNKED)
+  // tiles [0, ntiles) are walked whole (workgroup b: b, b+G, ...); tiles [ntiles, ntiles + nhalf/2) are cut in two
+  // 8-column halves, one per workgroup b < nhalf (tile ntiles + b/2, half b&1), as that workgroup's LAST item:
+  // 384 tiles (qkv of an 8B model) are 1.5 tiles for each of 256 workgroups instead of 2 for each of 192
+  int nhalf;
+  const int32_t *dyn;
+  RowSrc src[2];
   // EPI_F32
   float *out;  // [ksplit][MT*16][ldo]
   int ldo;
@@ -70,33 +75,56 @@ __device__ unsigned long long g_gstamps[8];
 #define GSTAMP(i)
 #endif
 
-// The GEMM of one launch as a device function, so that a cooperative multi-stage kernel can run
-// several of them back to back (k_mlp_fused below).  PRE: the weight fragments of the FIRST item
-// (tile blockIdx.x, chunk 0) were already requested by the caller into `pre` — across a grid
-// barrier, so that HBM keeps streaming while the workgroups meet.
+#ifndef DFL_EARLY_B   // A/B switch: 0 = item 1's weights are requested at the top of the loop (round 2), not in the prologue
+#define DFL_EARLY_B 0
+#endif
+#ifndef DFL_NORM_OWN  // A/B switch: 0 = a normalised source's sums of squares come from the producer's partials (round 2)
+#define DFL_NORM_OWN 0
+#endif
+#ifndef DFL_RAW_BARRIER  // A/B switch: 1 = a workgroup barrier between the issue of the rows' loads and the first weight request
+#define DFL_RAW_BARRIER 1
+#endif
+#ifndef DFL_NORM_WAIT  // A/B switch (scripts/ab_prof.sh): 0 = a normalised source's rows are not waited for before the weights
+#define DFL_NORM_WAIT 0
+#endif
+
 constexpr int gemm_fr(int MT, bool CHUNKED) { return CHUNKED ? 4 : (MT == 1 ? 8 : 4); }
 
-template <int MT, bool CHUNKED, int EPI, bool PRE = false>
-__device__ __forceinline__ void gemm_body(const GemmArgs &a, const bf16x8 *pre) {
+// One launch.  Order of the prologue (round 3; measured with scripts/dbg_gemm_stamps.py, scripts/ab_prof.sh and against
+// the pure-stream floor of scripts/probes/l2_prefetch_probe.hip — a stream of the same bytes in the same four launches
+// per layer takes 62 us where the round-2 kernels took 80):
+//   1. the activation side first: the wave's row fragments (8 KB, from L2) and, for a normalised source, one chunk of
+//      the RMSNorm weight (staged ONCE per workgroup in LDS instead of 32 VGPRs per lane).  Their addresses need the
+//      head of the argument block and the lane number only — no length (dependent scalar load) sits in front of them.
+//      A wave's vector loads return in issue order and, at a launch's start, everything requested behind the first
+//      weight burst queues behind ~32-64 MB in the memory system: asked for first, the rows are back after ~1.5 us and
+//      the sum of squares -> rstd -> normalise chain (1-2 us of VALU on 16 waves) runs UNDER the weight latency.
+//      (Tried the other way round, weights first: the rows came back 8 us later and the chain ran with HBM idle —
+//      gate/up 34.8 -> 36.6 us, qkv 14.3 -> 16.4 us in the cycle.)
+//   2. then item 0's weights, the residual value of the first tile, and item 1's weights — all BEFORE anything is
+//      waited for, so that two items are in flight while the chain runs;
+//   3. a normalised source's sum of squares is computed by the workgroup ITSELF from the rows it has just loaded
+//      (v_dot2c_f32_bf16; the whole K is in the workgroup): round 2 loaded the producer's per-tile partial sums, a
+//      dependent load that came back 5.6 us after its request with the burst already under way;
+//   4. only then the waits: lengths (scalar), rstd across the 16 waves, normalise, and the item loop.
+// Every load of the prologue is unconditional (clamped addresses, zero-length descriptors): a load under a branch
+// costs a vmcnt(0) at the join, i.e. the whole burst.
+// NORM = 1: the workgroup sees the whole K (gridDim.y == 1), so it sums the squares of the rows it has just loaded
+// ITSELF — no dependent load at all: the partial sums of squares a producer left in memory came back 5.6 - 8 us after
+// their request (queued behind every CU's first weight burst), with HBM idle behind them.  NORM = 2: K is cut over
+// grid.y (fp32-partial launches of the round-1 attention path): the row sums come from the producer's partials.
+template <int MT, bool CHUNKED, int EPI, int NORM>
+__device__ __forceinline__ void gemm_body(const GemmArgs &a) {
   GSTAMP(0);
   constexpr int FR = gemm_fr(MT, CHUNKED);
   // red[buf][wave][mt][256]: lane l owns floats 4l..4l+3 (its MFMA D regs)
   __shared__ float red[2][16][MT][256];
+  __shared__ float ssred[NORM ? MT : 1][16][16];
+  __shared__ bf16x8 nwl[NORM ? MT : 1][NORM ? 512 : 1];  // mode 2: the norm weight of K <= 4096, chunk c = elements 8c .. 8c+7
 
   const int tid = threadIdx.x;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l = tid & 63;
-
-  // ---- row validity (rows >= dyn[valid_word] count as zero): a scalar load, on its own counter
-  int nv[MT];
-  auto read_nv = [&]() {
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const RowSrc &s0 = a.src[mt];
-      nv[mt] = (s0.valid_word >= 0 && a.dyn) ? a.dyn[s0.valid_word] : 16;
-    }
-  };
-  if (CHUNKED) read_nv();  // the chunked kernel builds its activations inside load_item
 
   auto ks0_of = [&](int c) { return ((blockIdx.y * a.nch + c) * 16 + w) * a.nfr; };
   auto nf_of = [&](int c) {
@@ -104,25 +132,46 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &a, const bf16x8 *pre) 
     return nf < 0 ? 0 : (nf > a.nfr ? a.nfr : nf);
   };
 
-  bf16x8 xr[MT][FR];  // activations of the (single) chunk stay in registers for the launch
-
   // ---- tile sequence of this workgroup.  F32/ARGMAX/RESID: tiles bx, bx+G, ...
   // SILU: the packed weight interleaves (gate tile p, up tile p) and the sequence walks
   // pairs p = bx, bx+G, ... as gate,up,gate,up: the finishing thread meets a pair's two
   // sums in consecutive positions.
   const int stride = gridDim.x;
+  constexpr bool SILU = EPI == EPI_SILU || EPI == EPI_SILU_E;
+  constexpr bool moe = EPI == EPI_SILU_E;  // the tile sequence comes from the active-expert list (dependent scalar loads)
+  const int nwhole = (!SILU && (int)blockIdx.x < a.ntiles) ? (a.ntiles - 1 - (int)blockIdx.x) / stride + 1 : 0;  // whole tiles of this workgroup
+  const bool has_half = !SILU && (int)blockIdx.x < a.nhalf;
+  const int myhalf = (int)blockIdx.x & 1;
+  auto half_of = [&](int j) -> int { return (!SILU && j >= nwhole) ? myhalf : -1; };  // -1: a whole tile
+  auto tile_of = [&](int j) -> int {
+    if (!SILU) return j < nwhole ? (int)blockIdx.x + j * stride : a.ntiles + ((int)blockIdx.x >> 1);
+    int p = (int)blockIdx.x + (j >> 1) * stride;
+    if (moe) p = a.elist[p / a.npp] * a.npp + p % a.npp;  // scalar loads: p is uniform over the workgroup
+    return 2 * p + (j & 1);
+  };
+
+  bf16x8 wA[FR], wB[FR];
+  bf16x8 xA[MT][FR], xB[MT][FR];
+  bf16x8 xr[MT][FR];  // activations of the (single) chunk stay in registers for the launch
+
+  const int nf0 = nf_of(0);
+  const int ngroups = SILU ? a.ntiles >> 1 : a.ntiles;
   int nseq;
-  if (EPI == EPI_SILU) {
-    const int npairs = a.elist ? a.n_active[0] * a.npp : a.ntiles >> 1;
+  if (SILU) {
+    const int npairs = moe ? a.n_active[0] * a.npp : a.ntiles >> 1;
     nseq = (int)blockIdx.x < npairs ? 2 * ((npairs - 1 - (int)blockIdx.x) / stride + 1) : 0;
   } else {
-    nseq = (int)blockIdx.x < a.ntiles ? (a.ntiles - 1 - (int)blockIdx.x) / stride + 1 : 0;
+    nseq = nwhole + (has_half ? 1 : 0);
   }
-  auto tile_of = [&](int j) -> int {
-    if (EPI != EPI_SILU) return (int)blockIdx.x + j * stride;
-    int p = (int)blockIdx.x + (j >> 1) * stride;
-    if (a.elist) p = a.elist[p / a.npp] * a.npp + p % a.npp;  // scalar loads: p is uniform over the workgroup
-    return 2 * p + (j & 1);
+  const int nitems = nseq * a.nch;
+
+  int nv[MT];
+  auto read_nv = [&]() {  // row validity (rows >= dyn[valid_word] count as zero): scalar loads, on their own counter
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const RowSrc &s0 = a.src[mt];
+      nv[mt] = (s0.valid_word >= 0 && a.dyn) ? a.dyn[s0.valid_word] : 16;
+    }
   };
 
   // finishing thread f < MT*256: row m = (f&255)>>4, column nl = f&15 of the tile
@@ -132,40 +181,40 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &a, const bf16x8 *pre) 
   float gate_sum = 0.f;    // SILU: the pair's gate sum, kept across one position
   int arg_rows = 0;
 
-  // No guards on the k-step count anywhere: a runtime guard makes hipcc branch around every
-  // fragment load and wait vmcnt(0) after each (49 full waits instead of 16 in the SILU kernel,
-  // 34 -> 41 us).  load_ksteps clips at the wave's share through the buffer descriptor instead
-  // (zero weights, no traffic), and activations past the share are zero as well.
-  const int nf0 = nf_of(0);
-  auto load_item = [&](bf16x8(&wr)[FR], bf16x8(&xb)[MT][FR], int t, int c) {
-    if (!CHUNKED) {
-      load_ksteps<FR>(wr, a.wp + ((size_t)t * a.KS + ks0_of(0)) * 64, nf0, l);
-    } else {  // activation loads first, then the weights, then the masks (vmcnt is in order)
-      const int ks0 = ks0_of(c);
-      int ks[FR];
-      bool take[FR];
+  // chunked kernels: item (tile t, chunk c) = the wave's weights of that chunk AND its activation fragments
+  auto load_item_x = [&](bf16x8(&xb)[MT][FR], int c) {
+    const int ks0 = ks0_of(c);
+    int ks[FR];
+    bool take[FR];
 #pragma unroll
-      for (int f = 0; f < FR; ++f) {
-        take[f] = ks0 + f < a.KS;
-        ks[f] = take[f] ? ks0 + f : a.KS - 1;
-      }
-      bf16x8 raw[MT][FR], wv[MT][FR];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int f = 0; f < FR; ++f) wv[mt][f] = raw[mt][f] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) issue_x<FR, false>(a.src[mt], ks, l, nv[mt], raw[mt], wv[mt]);  // no mode 2 here
-      load_ksteps<FR>(wr, a.wp + ((size_t)t * a.KS + ks0) * 64, nf_of(c), l);
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) finish_x<FR, false>(a.src[mt], take, l, nv[mt], 1.f, raw[mt], wv[mt], xb[mt]);
+    for (int f = 0; f < FR; ++f) {
+      take[f] = ks0 + f < a.KS;
+      ks[f] = take[f] ? ks0 + f : a.KS - 1;
     }
+    bf16x8 raw[MT][FR], wv[MT][FR];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int f = 0; f < FR; ++f) wv[mt][f] = raw[mt][f] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) issue_x<FR, false>(a.src[mt], ks, l, nv[mt], raw[mt], wv[mt]);  // no mode 2 here
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) finish_x<FR, false>(a.src[mt], take, l, nv[mt], 1.f, raw[mt], wv[mt], xb[mt]);
+  };
+  auto load_item = [&](bf16x8(&wr)[FR], bf16x8(&xb)[MT][FR], int t, int c, int half) {
+    load_ksteps<FR>(wr, a.wp + ((size_t)t * a.KS + ks0_of(c)) * 64, nf_of(c), l, half);
+    if (CHUNKED) load_item_x(xb, c);  // the weights first (HBM), the activation fragments (L2) behind them
   };
 
   f32x4 acc[MT];
+  // EPI_RESID without a normalised source (o_proj, down_proj: one tile per workgroup): this thread's residual value
+  // of the FIRST tile, requested in the prologue
+  constexpr bool PREF = EPI == EPI_RESID && !NORM;
+  bf16_t resid0 = (bf16_t)0.f;
 
   auto finish = [&](int t, int pos) {
     const int buf = pos & 1;
+    const int hf = half_of(pos);  // a half tile: the other 8 columns belong to the neighbouring workgroup
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f32x4 *>(&red[buf][w][mt][l * 4]) = acc[mt];
     __syncthreads();
@@ -178,9 +227,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &a, const bf16x8 *pre) 
       float s = 0.f;
 #pragma unroll
       for (int ww = 0; ww < 16; ++ww) s += red[buf][ww][mt][idx];
+      const bool colok = hf < 0 || (nl >> 3) == hf;
       if (EPI == EPI_F32) {
-        a.out[((size_t)(blockIdx.y * MT + mt) * 16 + m) * a.ldo + t * 16 + nl] = s;
-      } else if (EPI == EPI_SILU) {
+        if (colok) a.out[((size_t)(blockIdx.y * MT + mt) * 16 + m) * a.ldo + t * 16 + nl] = s;
+      } else if (SILU) {
         if (buf == 0) {
           gate_sum = s;
         } else {
@@ -194,7 +244,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &a, const bf16x8 *pre) 
       } else if (EPI == EPI_ARGMAX) {
         const int n = t * 16 + nl;
         const float vb = rbf(s);  // lm_head output is bf16 before argmax (model/dflash.py:238,247)
-        const bool live = (m >= a.row0) && (m < a.row0 + arg_rows);
+        const bool live = (m >= a.row0) && (m < a.row0 + arg_rows) && colok;
         if (a.logits && live) a.logits[(size_t)m * a.N + n] = f2bf(s);
         // n grows along the sequence for a fixed thread: strict '>' keeps the first maximum
         if (live && (vb > best || bestn == 0x7fffffff)) {
@@ -208,9 +258,14 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &a, const bf16x8 *pre) 
         const int n = t * 16 + nl;
         const float v = rbf(s);  // the Linear's bf16 output
         bf16_t *hp = a.h_io + (int64_t)m * a.ldh + n;
-        const float hn = a.add_resid ? rbf(bf2f(*hp) + v) : v;
-        *hp = f2bf(hn);
-        if (a.tap) a.tap[(int64_t)m * a.ldtap + n] = f2bf(hn);
+        // the first tile's old value came with the prologue's loads (a dependent ~1 us load at the tail of the
+        // one-tile launches o_proj / down_proj otherwise); later tiles of a workgroup read theirs here
+        float hn = v;
+        if (a.add_resid) hn = rbf(bf2f((PREF && pos == 0) ? resid0 : *hp) + v);
+        if (colok) {
+          *hp = f2bf(hn);
+          if (a.tap) a.tap[(int64_t)m * a.ldtap + n] = f2bf(hn);
+        }
         const float q = row_sum16(hn * hn);  // the 16 threads of row m are one DPP row
         if (nl == 0 && a.ss_out) a.ss_out[t * 16 + m] = q;
       }
@@ -230,27 +285,30 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &a, const bf16x8 *pre) 
     if (!CHUNKED || c == a.nch - 1) finish(t, pos);
   };
 
-  // items (position j in the sequence, chunk c), weights double-buffered A/B
-  bf16x8 wA[FR], wB[FR];
-  bf16x8 xA[MT][FR], xB[MT][FR];
-  const int nitems = nseq * a.nch;
-  // ---- prologue (single-chunk kernels).  Order of issue: lengths (scalar) -> the activation
-  // side's vector loads (sums of squares, rows / fragments, norm weights) -> the first weights.
-  // A wave's vector loads return in issue order, so whatever is requested behind a weight burst
-  // is held back until the burst has landed; asked for first, the few KB of activations arrive
-  // within ~1 us and rstd / normalisation run UNDER the burst.
-  __shared__ float ssred[MT][16][16];
+  // the residual value of this thread's element of the FIRST tile (every thread asks: ff = tid & 255 — no branch)
+  auto ask_resid0 = [&]() {
+    if (PREF) {
+      const int ff = tid & 255;
+      resid0 = a.h_io[(int64_t)(ff >> 4) * a.ldh + (int)blockIdx.x * 16 + (ff & 15)];
+    }
+  };
+
+  // ---- (0) the lengths: dependent SCALAR loads (argument block -> dyn -> word), on their own counter and out of order
+  // with the vector loads — but through the same L2: requested behind the first weight burst they came back 5 - 9 us
+  // later (the "rstd prologue" of round 2 was mostly this wait).  Asked for before any vector load they cost nothing.
+  read_nv();
+  if (EPI == EPI_ARGMAX) {
+    arg_rows = a.nrows;
+    if (a.dyn && a.nrows_word >= 0) arg_rows = a.dyn[a.nrows_word] - a.row0;
+  }
+  __builtin_amdgcn_sched_barrier(0);
   float rstd[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) rstd[mt] = 1.f;
   if (!CHUNKED) {
-    read_nv();
-    if (EPI == EPI_ARGMAX) {
-      arg_rows = a.nrows;
-      if (a.dyn && a.nrows_word >= 0) arg_rows = a.dyn[a.nrows_word] - a.row0;
-    }
-    // (mode 2) the nss partial sums of squares of a row are summed by the 16 waves together:
-    // wave w takes partials w, w+16, ... (four unconditional loads in flight per lane per 256)
+    // ---- (1) the activation side, all unconditional: norm weight chunk (mode 2; any other mode reads 16 B of its own
+    // operand and ignores them), partial sums of squares, the wave's activation fragments, the residual value
+    bf16x8 nwv[MT];
     float ssv[MT][4];
     bool any_norm = false;
 #pragma unroll
@@ -258,8 +316,17 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &a, const bf16x8 *pre) 
       const RowSrc &s = a.src[mt];
 #pragma unroll
       for (int u = 0; u < 4; ++u) ssv[mt][u] = 0.f;
-      if (s.mode == 2) {
-        any_norm = true;
+      nwv[mt] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      if (NORM) {
+        const int c = min(tid & 511, a.KS * 4 - 1);
+        const char *nb = s.mode == 2 ? reinterpret_cast<const char *>(s.nw)
+                                     : (s.mode == 0 ? reinterpret_cast<const char *>(s.frag) : reinterpret_cast<const char *>(s.rows));
+        nwv[mt] = *reinterpret_cast<const bf16x8 *>(nb + c * 16);
+      }
+      if (NORM && s.mode == 2) any_norm = true;
+      if (NORM == 2 && s.mode == 2) {  // uniform (a kernel argument); the loads inside are clamped, not guarded
+        // the nss partial sums of squares of a row are summed by the 16 waves together:
+        // wave w takes partials w, w+16, ... (four loads in flight per lane per 256)
         const int m = l & 15, part = l >> 4;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -275,25 +342,82 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &a, const bf16x8 *pre) 
       take[f] = f < nf0;
       ks[f] = take[f] ? ks0_of(0) + f : 0;
     }
-    bf16x8 raw[MT][FR], wv[MT][FR];
+    bf16x8 raw[MT][FR], wv0[MT][FR];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int f = 0; f < FR; ++f) wv[mt][f] = raw[mt][f] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      for (int f = 0; f < FR; ++f) wv0[mt][f] = raw[mt][f] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) issue_x<FR>(a.src[mt], ks, l, nv[mt], raw[mt], wv[mt]);
-    if (PRE) {
-#pragma unroll
-      for (int f = 0; f < FR; ++f) wA[f] = pre[f];
-    } else if (nitems > 0) {
-      load_item(wA, xA, tile_of(0), 0);  // the first weights, behind the activations
+    for (int mt = 0; mt < MT; ++mt) issue_x<FR, false>(a.src[mt], ks, l, 16, raw[mt], wv0[mt]);
+    __builtin_amdgcn_sched_barrier(0);  // the ORDER of issue is the point: hipcc moved the weight requests in front
+    if (DFL_RAW_BARRIER && NORM == 0) {  // every wave's row requests enter the CU's in-order memory pipe before any weight request
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
     }
-    GSTAMP(1);
-    if (any_norm) {  // uniform over the workgroup: the modes are kernel arguments
+    auto own_ss = [&]() {  // NORM == 1: norm weight chunk and this wave's sums of squares -> LDS (waits for the rows)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const RowSrc &s = a.src[mt];
-        if (s.mode == 2) {
+        nwl[mt][tid & 511] = nwv[mt];
+        if (NORM == 1 && s.mode == 2) {  // this wave's share of the rows' sums of squares, from the fragments themselves
+          const int m = l & 15, part = l >> 4;
+          float t0 = 0.f, t1 = 0.f;  // v_dot2c_f32_bf16: two squares per instruction, no conversions, fp32 sums
+#pragma unroll
+          for (int f = 0; f < FR; ++f) {
+            const bf16x8 r = raw[mt][f];
+            float q0 = 0.f, q1 = 0.f;
+            q0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(r, r, 0, 1), __builtin_shufflevector(r, r, 0, 1), q0, false);
+            q1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(r, r, 2, 3), __builtin_shufflevector(r, r, 2, 3), q1, false);
+            q0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(r, r, 4, 5), __builtin_shufflevector(r, r, 4, 5), q0, false);
+            q1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(r, r, 6, 7), __builtin_shufflevector(r, r, 6, 7), q1, false);
+            t0 += take[f] ? q0 : 0.f;
+            t1 += take[f] ? q1 : 0.f;
+          }
+          float t = t0 + t1;
+          t += __shfl_xor(t, 16, 64);
+          t += __shfl_xor(t, 32, 64);
+          if (part == 0) ssred[mt][w][m] = t;
+        }
+      }
+    };
+    if (NORM == 1 && DFL_NORM_WAIT) {
+      // A normalised source WAITS for its rows here, before the first weight request: once any CU's burst is under
+      // way every load queues behind tens of MB, and all 16 waves meet at the barrier below.  One unloaded round trip
+      // (~1.2 us) now; the barrier / rstd / normalise chain then runs under the weights' latency.
+      own_ss();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- (2) item 0's weights.  No guards on the k-step count anywhere: a runtime guard makes hipcc branch around
+    // every fragment load and wait vmcnt(0) after each (49 full waits instead of 16 in the SILU kernel, 34 -> 41 us).
+    // load_ksteps clips at the wave's share through the buffer descriptor instead (zero weights, no traffic), and
+    // activations past the share are zero as well.  (The expert list of an MoE launch is a dependent scalar load: that
+    // launch asks for its first weights once it knows the tile.)
+    if (!moe)
+      load_ksteps<FR>(wA, a.wp + ((size_t)(SILU ? 2 * blockIdx.x : blockIdx.x) * a.KS + ks0_of(0)) * 64,
+                      (int)blockIdx.x < ngroups ? nf0 : 0, l);  // (the host cuts tiles in halves only behind whole ones)
+    else if (nitems > 0)
+      load_ksteps<FR>(wA, a.wp + ((size_t)tile_of(0) * a.KS + ks0_of(0)) * 64, nf0, l);
+    GSTAMP(6);
+    __builtin_amdgcn_sched_barrier(0);
+    ask_resid0();
+    // ---- (3) item 1's weights (a zero-length descriptor when the workgroup has a single item)
+    if (NORM == 1 && DFL_EARLY_B == 2 && !DFL_NORM_WAIT) {
+      own_ss();  // waits for the rows (asked for before the weights): item 1 is requested once they are back
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!moe && DFL_EARLY_B) {  // (the expert-list launch keeps item 1 for the loop: its tile index is another dependent scalar load)
+      const int t1 = nitems > 1 ? tile_of(1) : 0;
+      load_ksteps<FR>(wB, a.wp + ((size_t)t1 * a.KS + ks0_of(0)) * 64, nitems > 1 ? nf0 : 0, l, half_of(1));
+    }
+    GSTAMP(1);
+    // ---- (4) rstd, normalise
+    if (NORM == 1 && !DFL_NORM_WAIT && DFL_EARLY_B != 2) own_ss();
+    if (NORM && any_norm) {  // uniform over the workgroup: the modes are kernel arguments
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const RowSrc &s = a.src[mt];
+        if (NORM == 2) nwl[mt][tid & 511] = nwv[mt];  // both halves of the workgroup store the same 512 chunks
+        if (NORM == 2 && s.mode == 2) {
           const int m = l & 15, part = l >> 4;
           float v[4];
 #pragma unroll
@@ -326,34 +450,19 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &a, const bf16x8 *pre) 
     }
     GSTAMP(2);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) finish_x<FR>(a.src[mt], take, l, nv[mt], rstd[mt], raw[mt], wv[mt], xr[mt]);
+    for (int mt = 0; mt < MT; ++mt) {
+      if (NORM)
+        finish_xl<FR>(a.src[mt], ks, take, l, nv[mt], rstd[mt], raw[mt], nwl[mt], xr[mt]);
+      else
+        finish_x<FR, false>(a.src[mt], take, l, nv[mt], 1.f, raw[mt], wv0[mt], xr[mt]);
+    }
   } else {
-    if (EPI == EPI_ARGMAX) {
-      arg_rows = a.nrows;
-      if (a.dyn && a.nrows_word >= 0) arg_rows = a.dyn[a.nrows_word] - a.row0;
-    }
-    if (PRE) {  // weights of (tile 0, chunk 0) are in flight already: only the activations remain
-      const int ks0 = ks0_of(0);
-      int ks[FR];
-      bool take[FR];
-#pragma unroll
-      for (int f = 0; f < FR; ++f) {
-        take[f] = ks0 + f < a.KS;
-        ks[f] = take[f] ? ks0 + f : a.KS - 1;
-        wA[f] = pre[f];
-      }
-      bf16x8 raw[MT][FR], wv[MT][FR];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int f = 0; f < FR; ++f) wv[mt][f] = raw[mt][f] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) issue_x<FR, false>(a.src[mt], ks, l, nv[mt], raw[mt], wv[mt]);
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) finish_x<FR, false>(a.src[mt], take, l, nv[mt], 1.f, raw[mt], wv[mt], xA[mt]);
-    } else if (nitems > 0) {
-      load_item(wA, xA, tile_of(0), 0);
-    }
+    // chunked kernels build their activation fragments per item: item 0's behind the weights already requested
+    if (nitems > 0 || !moe)
+      load_ksteps<FR>(wA, a.wp + ((size_t)blockIdx.x * a.KS + ks0_of(0)) * 64, (int)blockIdx.x < ngroups ? nf0 : 0, l);
+    GSTAMP(6);
+    load_item_x(xA, 0);
+    ask_resid0();
     GSTAMP(1);
     GSTAMP(2);
   }
@@ -367,7 +476,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &a, const bf16x8 *pre) 
         cn = 0;
         ++jn;
       }
-      if (i + 1 < nitems) load_item(wB, xB, tile_of(jn), cn);
+      // (the single-chunk kernels requested item 1 in the prologue)
+      if (i + 1 < nitems && (CHUNKED || moe || !DFL_EARLY_B || i > 0)) load_item(wB, xB, tile_of(jn), cn, half_of(jn));
       process(wA, xA, tile_of(j), c, j);
       if (i == 0) GSTAMP(4);
       if (i + 1 >= nitems) break;
@@ -376,7 +486,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &a, const bf16x8 *pre) 
         c2 = 0;
         ++j2;
       }
-      if (i + 2 < nitems) load_item(wA, xA, tile_of(j2), c2);
+      if (i + 2 < nitems) load_item(wA, xA, tile_of(j2), c2, half_of(j2));
       process(wB, xB, tile_of(jn), cn, jn);
       if (i + 2 >= nitems) break;
       j = j2;
@@ -408,73 +518,21 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &a, const bf16x8 *pre) 
   }
 }
 
-template <int MT, bool CHUNKED, int EPI>
+template <int MT, bool CHUNKED, int EPI, int NORM>
 __global__ __launch_bounds__(1024) void k_gemm(GemmArgs a) {
-  gemm_body<MT, CHUNKED, EPI, false>(a, nullptr);
+  gemm_body<MT, CHUNKED, EPI, NORM>(a);
 }
 
-#ifdef DFL_EXPERIMENTAL_MLP  // built by scripts/probes/bench_mlp_fused.py only, never into the product library
-// ---- EXPERIMENT: two GEMM stages in one cooperative
-// launch — gate/up (SiLU epilogue) -> grid barrier -> down (residual epilogue) — with the second
-// stage's first weights requested BEFORE the barrier, so that HBM streams while the workgroups
-// meet.  One workgroup per CU (cooperative launch: all resident or the launch fails), a
-// hierarchical arrival counter (per-XCD slot = workgroup id % 8, then global), BOUNDED spin: a
-// workgroup that waits > 2 ms sets *fail and goes on (wrong numbers, never a hang).
-struct MlpArgs {
-  GemmArgs gu, down;
-  unsigned *bar;   // [1 + 8] counters, 128 B apart; monotonic: `epoch` = launches so far incl. this one
-  unsigned epoch;
-  int *fail;
-};
-
-__global__ __launch_bounds__(1024) void k_mlp_fused(MlpArgs m) {
-  const int tid = threadIdx.x;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l = tid & 63;
-  gemm_body<1, false, EPI_SILU, false>(m.gu, nullptr);
-
-  // ---- publish this workgroup's act columns: drain, then ONE agent-scope release
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  // ---- request the first item of the down stage (tile blockIdx.x, chunk 0): waves 1..15 now,
-  // wave 0 after the barrier (its atomics and polls would queue behind its own loads: vmcnt is
-  // in order)
-  constexpr int FR = gemm_fr(1, true);
-  const GemmArgs &d = m.down;
-  const int ks0 = (0 * 16 + w) * d.nfr;  // chunk 0 of a single-K-part grid
-  int nf = d.KS - ks0;
-  nf = nf < 0 ? 0 : (nf > d.nfr ? d.nfr : nf);
-  const bool has_tile = (int)blockIdx.x < d.ntiles;
-  bf16x8 pre[FR];
-#pragma unroll
-  for (int f = 0; f < FR; ++f) pre[f] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-  if (w != 0 && has_tile) load_ksteps<FR>(pre, d.wp + ((size_t)blockIdx.x * d.KS + ks0) * 64, nf, l);
-  if (tid == 0) {
-    const unsigned nwg = gridDim.x, x = blockIdx.x & 7, per = (nwg + 7 - x) / 8;
-    unsigned *cx = m.bar + 32 * (1 + x), *cg = m.bar;
-    const unsigned tk = __hip_atomic_fetch_add(cx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tk == m.epoch * per - 1) __hip_atomic_fetch_add(cg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned want = m.epoch * (nwg < 8 ? nwg : 8);
-    const unsigned long long t0 = wall_clock64();
-    while (__hip_atomic_load(cg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-      __builtin_amdgcn_s_sleep(1);
-      if (wall_clock64() - t0 > 200000ull) {
-        *m.fail = 1;
-        break;
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // this CU's L1 may hold stale act lines
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  if (w == 0 && has_tile) load_ksteps<FR>(pre, d.wp + ((size_t)blockIdx.x * d.KS + ks0) * 64, nf, l);
-  __builtin_amdgcn_s_barrier();  // raw: no vmcnt wait, the requested weights stay in flight
-  gemm_body<1, true, EPI_RESID, true>(m.down, pre);
+// the instantiation for this launch's row sources (a normalised source needs the NORM kernels)
+template <int MT, bool CHUNKED, int EPI>
+void launch_gemm(const GemmArgs &a, dim3 grid, hipStream_t stream) {
+  bool norm = false;
+  for (int mt = 0; mt < MT; ++mt) norm |= a.src[mt].mode == 2;
+  if (norm && !CHUNKED)   // fp32-partial launches may cut K over grid.y: the producer's partial sums; all others: own sums
+    hipLaunchKernelGGL((k_gemm<MT, CHUNKED, EPI, CHUNKED ? 0 : ((EPI == EPI_F32 || !DFL_NORM_OWN) ? 2 : 1)>), grid, dim3(1024), 0, stream, a);
+  else
+    hipLaunchKernelGGL((k_gemm<MT, CHUNKED, EPI, 0>), grid, dim3(1024), 0, stream, a);
 }
-#endif  // DFL_EXPERIMENTAL_MLP
 
 // Cross-workgroup finish of the fused argmax: one wave per row.  margin_out (optional):
 // top-1 minus top-2 logit of the row — the reference's only confidence statistic
@@ -564,6 +622,21 @@ extern "C" int dfl_debug_read_gemm_stamps(unsigned long long *host_out) {
 }
 #endif
 
+// Grid and tile split of a launch over `ntiles` column tiles (single K pass).  When the tiles do not divide over the
+// 256 CUs and the remainder is at most half a round (r <= 128), the last r tiles are cut in 8-column halves, one for
+// each of 2r workgroups: every CU streams within half a tile of the same byte count.  (qkv of an 8B model: 384 tiles =
+// 1.5 per workgroup on 256 CUs instead of 2 on 192 of them; lm_head: 9496 = 37 x 256 + 24.)
+static void plan_tiles(GemmArgs &a, int ntiles, bool allow_half, int &gx) {
+  gx = grid_x_for(ntiles);
+  a.ntiles = ntiles;
+  a.nhalf = 0;
+  const int r = ntiles % 256;
+  if (!allow_half || ntiles <= 256 || r == 0 || r > 128) return;
+  gx = 256;
+  a.ntiles = ntiles - r;
+  a.nhalf = 2 * r;
+}
+
 extern "C" int dfl_pack_weight(const void *w, void *wp, int N, int K, void *stream) {
   DFL_REQUIRE(w && wp, "dfl_pack_weight: null pointer");
   DFL_REQUIRE(N > 0 && K > 0 && N % 16 == 0 && K % 32 == 0, "dfl_pack_weight: need N%%16==0, K%%32==0 (N=%d K=%d)", N, K);
@@ -614,11 +687,13 @@ extern "C" int dfl_gemm_f32(const void *wp, const dfl_rows *x0, const dfl_rows *
   a.nch = 1;
   a.out = out;
   a.ldo = N;
-  dim3 grid(grid_x_for(a.ntiles, ksplit), ksplit);
+  int gx1 = 0;
+  if (ksplit == 1) plan_tiles(a, N / 16, true, gx1);
+  dim3 grid(ksplit == 1 ? gx1 : grid_x_for(a.ntiles, ksplit), ksplit);
   if (mt == 1)
-    hipLaunchKernelGGL((k_gemm<1, false, EPI_F32>), grid, dim3(1024), 0, (hipStream_t)stream, a);
+    launch_gemm<1, false, EPI_F32>(a, grid, (hipStream_t)stream);
   else
-    hipLaunchKernelGGL((k_gemm<2, false, EPI_F32>), grid, dim3(1024), 0, (hipStream_t)stream, a);
+    launch_gemm<2, false, EPI_F32>(a, grid, (hipStream_t)stream);
   DFL_CHECK_LAUNCH("dfl_gemm_f32");
   return DFL_OK;
 }
@@ -638,7 +713,7 @@ extern "C" int dfl_gemm_silu_mul(const void *wp_gateup, const dfl_rows *x, int I
   a.nfr = (KS + 15) / 16;
   a.nch = 1;
   a.act = (bf16_t *)act_frag;
-  hipLaunchKernelGGL((k_gemm<1, false, EPI_SILU>), dim3(grid_x_for(I / 16), 1), dim3(1024), 0, (hipStream_t)stream, a);
+  launch_gemm<1, false, EPI_SILU>(a, dim3(grid_x_for(I / 16), 1), (hipStream_t)stream);
   DFL_CHECK_LAUNCH("dfl_gemm_silu_mul");
   return DFL_OK;
 }
@@ -672,7 +747,7 @@ extern "C" int dfl_gemm_silu_mul_experts(const void *wp_gateup, int64_t wp_exper
   a.elist = list;
   a.n_active = n_active;
   a.npp = I / 16;
-  hipLaunchKernelGGL((k_gemm<1, false, EPI_SILU>), dim3(256, 1), dim3(1024), 0, (hipStream_t)stream, a);
+  launch_gemm<1, false, EPI_SILU_E>(a, dim3(256, 1), (hipStream_t)stream);
   DFL_CHECK_LAUNCH("dfl_gemm_silu_mul_experts");
   return DFL_OK;
 }
@@ -705,9 +780,10 @@ int gemm_argmax_impl(const void *wp, const dfl_rows *x, int V, int K, int row0, 
   a.best2_val = margin_out ? (float *)((char *)ws + 256 * 16 * (sizeof(float) + sizeof(int))) : nullptr;
   a.logits = (bf16_t *)logits;
   a.N = V;
-  const int gx = grid_x_for(a.ntiles);
+  int gx = 0;
+  plan_tiles(a, V / 16, true, gx);
   if (ev0) (void)hipEventRecord(ev0, (hipStream_t)stream);
-  hipLaunchKernelGGL((k_gemm<1, false, EPI_ARGMAX>), dim3(gx, 1), dim3(1024), 0, (hipStream_t)stream, a);
+  launch_gemm<1, false, EPI_ARGMAX>(a, dim3(gx, 1), (hipStream_t)stream);
   if (ev1) (void)hipEventRecord(ev1, (hipStream_t)stream);
   hipLaunchKernelGGL(k_argmax_finish, dim3(16), dim3(64), 0, (hipStream_t)stream, a.best_val, a.best_idx, a.best2_val, gx,
                      row0, nrows, dyn, nrows_dyn_word, out_ids, out_off, margin_out);
@@ -730,63 +806,6 @@ extern "C" int dfl_gemm_argmax_timed(const void *wp, const dfl_rows *x, int V, i
                           (hipEvent_t)ev_start, (hipEvent_t)ev_end, stream);
 }
 
-#ifdef DFL_EXPERIMENTAL_MLP
-/* EXPERIMENT (scripts/probes/bench_mlp_fused.py): dfl_gemm_silu_mul + dfl_gemm_resid(add_residual) of one MLP as
- * ONE launch, see k_mlp_fused.  bar_ws: 4096 zeroed bytes; epoch 1, 2, 3, ... per launch (top bit: plain instead of
- * cooperative launch); the int at bar_ws + 2048 becomes 1 if a workgroup gave up waiting. */
-extern "C" int dfl_mlp_fused(const void *wp_gateup, const dfl_rows *x, int I, int K, void *act_frag, const void *wp_down,
-                             int N, void *h_io, int64_t ldh, float *ss_out, const int32_t *dyn, void *bar_ws,
-                             unsigned epoch, void *stream) {
-  DFL_REQUIRE(wp_gateup && act_frag && wp_down && h_io && bar_ws, "dfl_mlp_fused: null pointer");
-  DFL_REQUIRE(I > 0 && K > 0 && I % 32 == 0 && K % 32 == 0 && N % 16 == 0 && K / 32 <= 128 && I / 32 > 128,
-              "dfl_mlp_fused: shapes outside the experiment (need K <= 4096 < I)");
-  MlpArgs m{};
-  if (!fill_src(m.gu.src[0], x, K, "dfl_mlp_fused")) return DFL_EINVAL;
-  m.gu.wp = (const bf16x8 *)wp_gateup;
-  m.gu.dyn = dyn;
-  m.gu.KS = K / 32;
-  m.gu.ntiles = 2 * (I / 16);
-  m.gu.nfr = (m.gu.KS + 15) / 16;
-  m.gu.nch = 1;
-  m.gu.act = (bf16_t *)act_frag;
-  dfl_rows actsrc{};
-  actsrc.frag = act_frag;
-  actsrc.valid_word = -1;
-  actsrc.mode = 0;
-  if (!fill_src(m.down.src[0], &actsrc, I, "dfl_mlp_fused")) return DFL_EINVAL;
-  m.down.wp = (const bf16x8 *)wp_down;
-  m.down.dyn = dyn;
-  m.down.KS = I / 32;
-  m.down.ntiles = N / 16;
-  m.down.nfr = 4;
-  m.down.nch = (m.down.KS + 63) / 64;
-  m.down.h_io = (bf16_t *)h_io;
-  m.down.ldh = ldh;
-  m.down.add_resid = 1;
-  m.down.ss_out = ss_out;
-  const int g1 = grid_x_for(I / 16), g2 = grid_x_for(m.down.ntiles);
-  DFL_REQUIRE(g1 == g2, "dfl_mlp_fused: the two stages want different grids (%d vs %d)", g1, g2);
-  m.bar = (unsigned *)bar_ws;
-  m.epoch = epoch;
-  m.fail = (int *)((char *)bar_ws + 2048);
-  // epoch's top bit selects a PLAIN launch (experiment: the cooperative launch path itself costs
-  // ~25 us here); residency of all 256 workgroups is then an assumption (one per CU, idle GPU),
-  // backed only by the bounded spin
-  if (epoch & 0x80000000u) {
-    m.epoch = epoch & 0x7fffffffu;
-    hipLaunchKernelGGL(k_mlp_fused, dim3(g1), dim3(1024), 0, (hipStream_t)stream, m);
-    DFL_CHECK_LAUNCH("dfl_mlp_fused");
-    return DFL_OK;
-  }
-  void *args[] = {&m};
-  const hipError_t e = hipLaunchCooperativeKernel((const void *)k_mlp_fused, dim3(g1), dim3(1024), args, 0, (hipStream_t)stream);
-  if (e != hipSuccess) {
-    dfl_set_error("dfl_mlp_fused: cooperative launch failed: %s", hipGetErrorString(e));
-    return DFL_ELAUNCH;
-  }
-  return DFL_OK;
-}
-#endif  // DFL_EXPERIMENTAL_MLP
 
 extern "C" int dfl_gemm_resid(const void *wp, const dfl_rows *x, int N, int K, void *h_io, int64_t ldh,
                               int add_residual, void *tap, int64_t ldtap, float *ss_out, const int32_t *dyn,
@@ -807,16 +826,19 @@ extern "C" int dfl_gemm_resid(const void *wp, const dfl_rows *x, int N, int K, v
   a.tap = (bf16_t *)tap;
   a.ldtap = ldtap;
   a.ss_out = ss_out;
-  const dim3 grid(grid_x_for(a.ntiles), 1);
+  int gx = 0;
+  // (a half tile has no slot of its own in ss_out: launches that leave sums of squares keep whole tiles)
+  plan_tiles(a, N / 16, KS <= 16 * 8 && !ss_out, gx);
+  const dim3 grid(gx, 1);
   if (KS <= 16 * 8) {  // the whole K fits the 16 waves x 8 steps of one pass
     a.nfr = (KS + 15) / 16;
     a.nch = 1;
-    hipLaunchKernelGGL((k_gemm<1, false, EPI_RESID>), grid, dim3(1024), 0, (hipStream_t)stream, a);
+    launch_gemm<1, false, EPI_RESID>(a, grid, (hipStream_t)stream);
   } else {  // walk K in chunks of 16 waves x 4 steps inside the workgroup
     DFL_REQUIRE(a.src[0].mode != 2, "dfl_gemm_resid: a normalised source needs K <= 4096");
     a.nfr = 4;
     a.nch = (KS + 63) / 64;
-    hipLaunchKernelGGL((k_gemm<1, true, EPI_RESID>), grid, dim3(1024), 0, (hipStream_t)stream, a);
+    launch_gemm<1, true, EPI_RESID>(a, grid, (hipStream_t)stream);
   }
   DFL_CHECK_LAUNCH("dfl_gemm_resid");
   return DFL_OK;

@@ -222,25 +222,27 @@ class DecodeSession:
             posterior = sample(out.logits, self.temperature)
         # ---- accept scan + commit + bookkeeping on the device (:258-268)
         if not (bs > 1 and draft_steps == 1):
-            # (after a cached draft forward the record already holds start = pos0 + tau and cleared stop / cycle words:
-            # draft_block's dfl_set_dyn2 wrote them into this very buffer)
+            # (after a cached draft forward the record already holds start = pos0 + tau: either draft_block's
+            # dfl_set_dyn2 wrote it — which also clears the stop / cycle words — or, on the dyn_ready steady state, the
+            # previous cycle's accept kernel did.  STOP is sticky and CYCLE keeps counting across steady-state cycles:
+            # a stopped session is terminal, run_decode leaves the loop on it)
             ops.set_dyn(self.dyn, 0, 0, bs, start)  # start word = pos0 + tau = start
         if self.poll_result:
-            self._res_np[1] = -1
+            self._res_np[3] = -1   # the cycle counter (>= 1 once written) is the kernel's LAST store, behind a release
         ops.accept_commit(blk[0], posterior[0].contiguous(), bs, self.output_ids[0], self.dyn, self.stop_t,
                           self.result, rearm=(self.block[0], self.max_bs, self.mask_token_id))
         self._armed = True
         # the record now holds the next draft forward's S / tau / pos0 / start — if that cycle was a cached draft cycle
         # on this record (bs > 1, one draft step) and keeps the block size
         self._dyn_bs = bs if (bs > 1 and draft_steps == 1 and self.use_draft) else None
-        if self.poll_result:   # the cycle's one device->host hand-over: the kernel's 16-byte store into pinned memory
+        if self.poll_result:   # the cycle's one device->host hand-over: pinned memory, polled on the word written last
             t0 = time.perf_counter()
-            while self._res_np[1] == -1:
+            while self._res_np[3] == -1:
                 if time.perf_counter() - t0 > 0.05:   # a long verify: stop burning the core, block on the stream
                     torch.cuda.current_stream().synchronize()
-                    if self._res_np[1] == -1:
+                    if self._res_np[3] == -1:
                         raise RuntimeError("dfl_accept_commit: the result never arrived in host memory")
-            res = self._res_np.tolist()
+            res = self._res_np.tolist()   # words 0..2 were stored before the counter was released: read them now
         else:
             res = self.result.tolist()  # device->host copy (synchronises the stream)
         tau = res[0] + 1

@@ -121,6 +121,9 @@ class NativeTarget:
                   "q_norm": w(p + "self_attn.q_norm.weight") if has_qk else None,
                   "k_norm": w(p + "self_attn.k_norm.weight") if has_qk else None,
                   "ln1": w(p + "input_layernorm.weight"), "ln2": w(p + "post_attention_layernorm.weight")}
+            if (p + "mlp.experts.0.gate_proj.weight") in sd:   # per-expert ModuleList layout (older transformers)
+                raise NotImplementedError("NativeTarget: per-expert ModuleList MoE weights (mlp.experts.{e}.gate_proj) are "
+                                          "not supported, only the fused gate_up_proj / down_proj tensors; keep the HF target")
             if (p + "mlp.experts.gate_up_proj") in sd:       # sparse-MoE layer
                 gup, dwn = w(p + "mlp.experts.gate_up_proj"), w(p + "mlp.experts.down_proj")   # [E, 2I, H], [E, H, I]
                 Ie = self.Ie
@@ -182,6 +185,7 @@ class NativeTarget:
             self.src["xn"] = [ops.rows_frag(ws["xn"][t]) for t in range(NT)]
             self.src["xn1"] = [ops.rows_frag(ws["xn1"][t]) for t in range(NT)]
         self.debug_routing = None
+        self.gu_events = None   # (layer, start, end): torch.cuda.Event pair recorded around that layer's gate/up GEMM launch
         self._rope = None
         self._taps = {}
         torch.cuda.synchronize(dev)
@@ -350,7 +354,8 @@ class NativeTarget:
         cos, sin = self._rope_tab(start + bs + 64)
         # the verify's kernels read only the tiles' valid-row counts from the record (the attention takes immediates):
         # it is rewritten when the block size changes, not every cycle
-        if getattr(cache, "_dyn_bs", None) != bs:
+        # — the round-1 fused stage (attn_impl="fused") reads S / TAU / POS0 from the record: rewritten every call there
+        if self.attn_impl != "head" or getattr(cache, "_dyn_bs", None) != bs:
             ops.set_dyn2(cache.dyn, start, 0, bs, start)
             cache._dyn_bs = bs
         dyn = cache.dyn[:8]
@@ -412,8 +417,13 @@ class NativeTarget:
             if prev_moe:
                 self._moe_mlp(i, lw, tiles, hrow, taps, sl)
             else:
+                gev = self.gu_events if (self.gu_events is not None and self.gu_events[0] == i) else None
+                if gev is not None:       # bench.py: this layer's gate/up launch between two events on the launch stream
+                    gev[1].record()
                 for t, dt in tiles:
                     ops.gemm_silu_mul(lw["gu"], src["ln2"][i][t], self.I, H, ws["act"][t], dt)
+                if gev is not None:
+                    gev[2].record()
                 for t, dt in tiles:
                     tap = taps[16 * t:16 * t + 16, sl[0] * H:(sl[0] + 1) * H] if sl else None
                     ops.gemm_resid(lw["down"], src["act"][t], H, self.I, hrow[t], add_residual=True,

@@ -332,7 +332,9 @@ int dfl_argmax(const void *logits, int dtype, int rows, int64_t V, int64_t *ids,
  *   output_ids[start .. start+acc] = block[0..acc]; output_ids[start+acc+1] = posterior[acc]
  *   dyn: S <- start, tau <- acc+1, pos0 <- start, start <- start+acc+1, cycle++, stop |= any stop id
  *        among the acc+2 tokens just written
- * result (int32[4], may be pinned host memory mapped to the device): {acc, new_start, stop, cycle}. */
+ * result (int32[4], may be pinned host memory mapped to the device): {acc, new_start, stop, cycle}; words 0..2 are
+ * stored first, the cycle counter (>= 1) last behind a system-scope release: a polling host waits for word 3 to change
+ * and reads the others afterwards. */
 int dfl_accept_commit(const int64_t *block_ids, const int64_t *posterior, int bs, int64_t *output_ids,
                       int64_t output_len, int32_t *dyn, const int64_t *stop_ids, int n_stop, int32_t *result,
                       void *stream);

@@ -31,7 +31,7 @@ normed = ops.rows_normed(h, ss, 256, nw, 1e-6, ops.DYN_BS)
 fragH = ops.rows_frag(torch.randn(16 * H, device=dev).to(BF16))
 fragI = ops.rows_frag(torch.randn(16 * I, device=dev).to(BF16))
 big = torch.empty(600_000_000, dtype=torch.uint8, device=dev)
-names = ["first loads issued", "rstd prologue", "build x", "first item done", "loop", "tail"]
+names = ["prologue loads issued", "lengths + rstd", "build x", "first item done", "loop", "tail"]
 
 
 def run(label, fn):
@@ -47,7 +47,7 @@ def run(label, fn):
         assert dbg.dfl_debug_read_gemm_stamps(st) == 0
         t = [st[i] for i in range(6)]
         d = [(t[i + 1] - t[i]) / 100.0 for i in range(5)]
-        print(f"{label:28s} rep {rep}: " + "  ".join(f"{n}={x:.2f}" for n, x in zip(names, d)) +
+        print(f"{label:28s} rep {rep}: first weights asked={(st[6] - st[0]) / 100.0:.2f}  " + "  ".join(f"{n}={x:.2f}" for n, x in zip(names, d)) +
               f"  | wg0 total {(t[5] - t[0]) / 100.0:.2f} us, events {t0.elapsed_time(t1) * 1e3:.1f} us")
 
 

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Turn a pmc_summary.py CSV into profiles/<round>_pmc_kernels.json: the HBM bytes per launch of the kernels bench.py's
+`roofline` object names (gate/up GEMM + SiLU epilogue = k_gemm<1, false, 1>, the largest share of the cycle; lm_head GEMM
++ fused argmax = k_gemm<1, false, 2>), stamped with the hash of the sources the kernels are built from so that bench.py
+can refuse the numbers once a kernel has changed.
+usage: pmc_kernels_json.py <summary.csv> <out.json>"""
+import csv, hashlib, json, os, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNEL_SOURCES = ["dflash_amd/csrc/gemm_skinny.hip", "dflash_amd/csrc/gemm_rows.h", "dflash_amd/csrc/dfl_common.h"]
+KERNELS = {"gate_up": ("k_gemm<1,false,1>", 2 * 12288 * 4096 * 2), "lm_head": ("k_gemm<1,false,2>", 151936 * 4096 * 2)}
+
+
+def source_hash():
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+if __name__ == "__main__":
+    allrows = list(csv.DictReader(open(sys.argv[1])))
+    out = {"kernels": {}, "source": os.path.relpath(sys.argv[1], ROOT), "kernel_source_sha256_16": source_hash(),
+           "kernel_sources": KERNEL_SOURCES,
+           "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (scripts/profile_gpu.sh pmc); "
+                     "hbm = 2 * FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE counts half of a wide coalesced read, "
+                     "MI355X_MICROARCH.md, HBM)"}
+    for key, (kname, alg) in KERNELS.items():
+        rows = [r for r in allrows if r["kernel"].replace(" ", "") == kname]
+        if not rows:
+            continue
+        r = max(rows, key=lambda x: int(x["dispatches"]))
+        out["kernels"][key] = {"kernel": r["kernel"], "fetch_size_kb": float(r["FETCH_SIZE_KB_mean"]),
+                               "write_size_kb": float(r["WRITE_SIZE_KB_mean"]),
+                               "hbm_bytes_per_launch": int(r["hbm_bytes_corrected"]), "algorithmic_bytes": alg,
+                               "traffic_over_algorithmic": int(r["hbm_bytes_corrected"]) / alg,
+                               "dispatches": int(r["dispatches"])}
+    json.dump(out, open(sys.argv[2], "w"), indent=1)
+    print(json.dumps(out))

@@ -29,10 +29,15 @@ def test_bench_line_contract_small():
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["lossless_fraction"] == 1.0 and d["value"] > 0
-    rf = d["roofline"]
-    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.5 < rf["frac"] < 1.0
-    assert 0.15 < rf["avg_ms"] < 0.25          # the lm_head GEMM alone (1.245 GB), not the launch pair
+    rf = d["roofline"]                          # the kernel with the largest share of the cycle: the gate/up GEMM
+    lm = rf["also"][0]                          # beside it: the lm_head GEMM + fused argmax
+    for r in (rf, lm):
+        assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.5 < r["frac"] < 1.0
+    assert "EPI_SILU" in rf["kernel"] and rf["bytes_per_launch"] == 2 * 12288 * 4096 * 2
+    assert 0.025 < rf["avg_ms"] < 0.05         # one gate/up launch (201 MB), not a whole layer
+    assert 0.15 < lm["avg_ms"] < 0.25          # the lm_head GEMM alone (1.245 GB), not the launch pair
+    assert d["value_per_gpu"] == d["value"]
 
 
 def test_two_rank_flow_rehearsed_on_one_gpu():

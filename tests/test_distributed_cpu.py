@@ -80,6 +80,20 @@ def test_bench_gpus_flag_launches_that_many_ranks():
     assert lines[0]["value"] is None             # a selftest never reports a measurement
 
 
+def test_bench_baseline_config2_shape_eight_ranks_four_requests_each():
+    """BASELINE.json configs[2] in one command — `--gpus 8 --requests-per-gpu 4` — through the launcher with eight gloo
+    ranks on the host (benchmark.py:445 shards 32 prompts over 8 ranks; run_benchmark.sh:120-133 starts them): the line
+    reports the 8-rank world, 32 requests, dp8, a per-GPU key beside the all-rank sum."""
+    rc, lines, err = _run_bench(["--gpus", "8", "--requests-per-gpu", "4", "--steps", "2", "--warmup", "0", "--selftest-cpu"],
+                                {"OMP_NUM_THREADS": "1"})
+    assert rc == 0, err
+    assert len(lines) == 1, lines
+    ln = lines[0]
+    assert ln["n_gpus"] == 8 and ln["config"]["requests"] == 32 and ln["config"]["parallelism"] == "dp8"
+    assert ln["cycles_all_ranks"] == 16.0
+    assert "value_per_gpu" in ln and ln["value"] is None and ln["value_per_gpu"] is None
+
+
 def test_bench_rejects_a_world_that_differs_from_gpus():
     rc, lines, err = _run_bench(["--gpus", "2", "--selftest-cpu"],
                                 {"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",

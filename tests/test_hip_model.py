@@ -281,6 +281,54 @@ def test_native_target_end_to_end_lossless_walk():
     assert runs["native"].acceptance_lengths == exp
 
 
+def test_round1_attention_stage_over_several_verifies():
+    """NativeTarget(attn_impl="fused") — the round-1 stage that reads S / tau / pos0 from the cache's length record —
+    over MANY verifies of one cache with an unchanged block size: the record must be rewritten every call (a record
+    left at the first cycle's start position gives wrong RoPE / append rows from the second verify on).  Committed ids
+    = the target's greedy walk, acceptance lengths = the 'head' stage's."""
+    from dflash_amd import NativeTarget, dflash_generate
+    from dflash_amd.synthetic import greedy_walk, impose_greedy_walk
+    cfg = H.tiny_cfg()
+    m = make_model(cfg)
+    hf = _tiny_hf()
+    perm = impose_greedy_walk(hf, seed=8)
+    prompt = torch.randint(0, 2000, (1, 37), generator=torch.Generator().manual_seed(12)).to(dev())
+    n_new = 90
+    G = greedy_walk(perm, prompt, n_new + 40).to(dev())
+    plan = H.make_plan(64, 16, 23)
+
+    def hook(blk, start, call):
+        k = min(plan[call], blk.shape[1] - 1)
+        blk[0, 1:k + 1] = G[start + 1:start + k + 1]
+        if k + 1 < blk.shape[1]:
+            w = G[start + k + 1]
+            blk[0, k + 1] = torch.where(blk[0, k + 1] == w, (w + 1) % 2000, blk[0, k + 1])
+
+    runs = {}
+    for impl in ("head", "fused"):
+        r = dflash_generate(m, NativeTarget(hf, attn_impl=impl), prompt, cfg.mask_token_id, n_new, 16, None, 0.0,
+                            draft_token_hook=hook)
+        assert r.output_ids[0].tolist() == G[:37 + n_new].tolist(), impl
+        assert len(r.acceptance_lengths) > 5
+        runs[impl] = r
+    assert runs["head"].acceptance_lengths == runs["fused"].acceptance_lengths
+    # and verify by verify on one cache: posterior ids and appended K rows of the two stages, three blocks in a row
+    res = {}
+    for impl in ("head", "fused"):
+        tgt = NativeTarget(hf, attn_impl=impl)
+        cache = tgt.new_cache(256)
+        tgt.prefill(G[None, :30], cache)
+        posts = []
+        for c in range(3):
+            s0 = 30 + 16 * c
+            post, _ = tgt.verify(G[s0:s0 + 16].contiguous(), s0, cache)
+            posts.append(post.clone())
+        res[impl] = (posts, cache.k[2][:, :78].clone())
+    for a, b in zip(res["head"][0], res["fused"][0]):
+        assert torch.equal(a, b)
+    H.assert_close("K rows layer 2 over three verifies, fused vs head", res["fused"][1], res["head"][1], max_rel=H.KV_MAX_REL)
+
+
 def test_fused_attention_oproj_launch_is_equivalent():
     """fuse_oproj = True (dfl_attn_head_oproj: attention stage + o_proj in one launch, opt-in because it measured
     slower): the native verify's posterior ids and taps and the draft's block tokens agree with the two-launch
@@ -719,7 +767,7 @@ def test_wide_draft_one_pass_equals_two_passes(bs, tau):
     H.assert_close(f"wide draft K bs {bs}", a[1][0], b[1][0], max_rel=H.KV_MAX_REL)
     H.assert_close(f"wide draft V bs {bs}", a[1][1], b[1][1], max_rel=H.KV_MAX_REL)
     H.assert_close(f"wide draft logits bs {bs}", a[2], b[2])
-    H.assert_ids_match_where_safe(f"wide draft ids bs {bs}", a[3][1:], b[2].float(), min_safe=0)
+    H.assert_ids_match_where_safe(f"wide draft ids bs {bs}", a[3][1:], b[2].float(), min_safe=1)
 
 
 @pytest.mark.parametrize("one_pass", [True, False])

@@ -13,10 +13,10 @@ def dev():
     return torch.device("cuda", 0)
 
 
-def _moe_hf(layers=4, E=16, top_k=4, Ie=256, mlp_only=(), dtype=BF16, seed=41, norm_topk=True):
+def _moe_hf(layers=4, E=16, top_k=4, Ie=256, mlp_only=(), dtype=BF16, seed=41, norm_topk=True, hidden=512, heads=4, kv=2):
     tf = pytest.importorskip("transformers")
-    cfg = tf.Qwen3MoeConfig(vocab_size=2048, hidden_size=512, intermediate_size=1024, moe_intermediate_size=Ie,
-                            num_hidden_layers=layers, num_attention_heads=4, num_key_value_heads=2, head_dim=128,
+    cfg = tf.Qwen3MoeConfig(vocab_size=2048, hidden_size=hidden, intermediate_size=2 * hidden, moe_intermediate_size=Ie,
+                            num_hidden_layers=layers, num_attention_heads=heads, num_key_value_heads=kv, head_dim=128,
                             num_experts=E, num_experts_per_tok=top_k, decoder_sparse_step=1, norm_topk_prob=norm_topk,
                             max_position_embeddings=4096, rms_norm_eps=1e-6, tie_word_embeddings=False,
                             rope_parameters={"rope_type": "default", "rope_theta": 1e6}, mlp_only_layers=list(mlp_only))
@@ -36,6 +36,14 @@ def _moe_hf(layers=4, E=16, top_k=4, Ie=256, mlp_only=(), dtype=BF16, seed=41, n
     return m.eval()
 
 
+def _tie_free_logits(rows, E, g):
+    """bf16 router logits in about +-9 with no two equal values in a row (random bf16 draws tie: 8 mantissa bits), so the
+    top-k selection of every row is unambiguous in any correct implementation."""
+    pool = torch.unique((torch.randn(20000, generator=g) * 3).to(BF16))
+    assert pool.numel() >= E
+    return torch.stack([pool[torch.randperm(pool.numel(), generator=g)[:E]] for _ in range(rows)])
+
+
 @pytest.mark.parametrize("E,top_k,norm", [(16, 4, True), (128, 8, True), (24, 2, False), (200, 8, True)])
 def test_moe_route_matches_torch(E, top_k, norm):
     """dfl_moe_route vs Qwen3MoeTopKRouter.forward's arithmetic (fp32 softmax of the bf16 logits, top-k, renormalise,
@@ -44,7 +52,7 @@ def test_moe_route_matches_torch(E, top_k, norm):
     g = torch.Generator().manual_seed(E + top_k)
     ep = (E + 15) // 16 * 16
     logits = torch.zeros(16, ep, dtype=BF16)
-    logits[:, :E] = (torch.randn(16, E, generator=g) * 3).to(BF16)
+    logits[:, :E] = _tie_free_logits(16, E, g)
     rows = 11
     dyn = torch.zeros(8, dtype=torch.int32, device=dev())
     ops.set_dyn(dyn, 0, 0, rows, 0)
@@ -65,7 +73,7 @@ def test_moe_route_matches_torch(E, top_k, norm):
             ok_rows.append(m)
         ref[m, i[m]] = v[m].to(BF16).float()
     got = wt.float().cpu()
-    assert len(ok_rows) >= rows // 2          # (bf16 logits tie: with 200 experts several rows have equal top-9 values)
+    assert len(ok_rows) == rows               # the logits are tie-free by construction: every row is checked
     assert torch.equal(got[rows:], torch.zeros(16 - rows, E))
     for m in ok_rows:
         assert (got[m] != 0).sum() == top_k
@@ -122,25 +130,95 @@ def test_grouped_expert_gemms_match_torch(pair_kernel):
     assert (got - ref).abs().mean() <= 3e-3 * ref.abs().max()
 
 
+@pytest.mark.parametrize("pair_kernel", [False, True])
+def test_expert_kernels_at_30b_a3b_shapes(pair_kernel):
+    """BASELINE configs[4] at its REAL expert geometry (Qwen3-Coder-30B-A3B: H 2048, moe_intermediate 768, 128 experts,
+    top-8): dfl_moe_route -> dfl_moe_gate_up / dfl_gemm_silu_mul_experts -> dfl_moe_down on 16 rows with a balanced
+    routing spread (~80 active experts), against torch's router arithmetic and the fp32 experts loop
+    (tf:models/qwen3_moe/modeling_qwen3_moe.py, Qwen3MoeExperts.forward)."""
+    from dflash_amd import ops
+    g = torch.Generator().manual_seed(30)
+    E, I, Hd, rows, top_k = 128, 768, 2048, 16, 8
+    gu = (torch.randn(E, 2 * I, Hd, generator=g) * 0.03).to(BF16).to(dev())
+    dn = (torch.randn(E, Hd, I, generator=g) * 0.03).to(BF16).to(dev())
+    x = torch.randn(16, Hd, generator=g).to(BF16).to(dev())
+    logits = _tie_free_logits(16, E, g)
+    dyn = torch.zeros(8, dtype=torch.int32, device=dev())
+    ops.set_dyn(dyn, 0, 0, rows, 0)
+    wt = torch.zeros(16, E, dtype=BF16, device=dev())
+    active = torch.zeros(E, dtype=torch.int32, device=dev())
+    lst = torch.zeros(E, dtype=torch.int32, device=dev())
+    n = torch.zeros(1, dtype=torch.int32, device=dev())
+    ops.moe_route(logits.to(dev()), E, top_k, True, wt, active, lst, n, dyn=dyn, dyn_word=ops.DYN_BS)
+    p = torch.softmax(logits.float(), dim=-1)
+    v, i = torch.topk(p, top_k, dim=-1)
+    v = (v / v.sum(dim=-1, keepdim=True)).to(BF16)
+    wref = torch.zeros(16, E, dtype=BF16)
+    wref[torch.arange(16)[:, None], i] = v
+    assert torch.equal((wt != 0).cpu(), wref != 0)
+    assert torch.allclose(wt.float().cpu(), wref.float(), rtol=2 ** -7, atol=1e-4)
+    k = int(n)
+    assert 60 <= k <= 100, k                       # a balanced spread, as a real router gives on 16 rows x top-8
+    gu_p = torch.stack([ops.pack_weight_gateup(gu[e, :I].contiguous(), gu[e, I:].contiguous()) for e in range(E)])
+    dn_p = torch.stack([ops.pack_weight(dn[e].contiguous()) for e in range(E)])
+    xf = torch.empty(16 * Hd, dtype=BF16, device=dev())
+    ops.pack_rows(x, 16, xf)
+    act = torch.full((E, 16 * I), float("nan"), dtype=BF16, device=dev())
+    if pair_kernel:
+        ops.moe_gate_up(gu_p, xf, E, I, Hd, act, lst, n)
+    else:
+        ops.gemm_silu_mul_experts(gu_p, ops.rows_frag(xf), E, I, Hd, act, lst, n)
+    out = torch.zeros(2, 16, Hd, dtype=torch.float32, device=dev())
+    ops.moe_down(dn_p, act, wt, lst, n, E, Hd, I, 2, out)
+    got = out.sum(0)
+    ref = torch.zeros(16, Hd, device=dev())
+    worst_act = 0.0
+    for e in range(E):
+        if not active[e]:
+            assert torch.isnan(act[e].float()).all()
+            continue
+        gate, up = (x.float() @ gu[e].float().T).to(BF16).chunk(2, dim=-1)
+        a = (torch.nn.functional.silu(gate.float()).to(BF16).float() * up.float()).to(BF16)
+        ref += wt[:, e].float()[:, None] * (a.float() @ dn[e].float().T)
+        # the expert's own activation tile, frag16 [I/8][16][8] -> rows
+        got_a = act[e].view(I // 8, 16, 8).permute(1, 0, 2).reshape(16, I).float()
+        worst_act = max(worst_act, float((got_a - a.float()).abs().max() / a.float().abs().max()))
+    assert worst_act <= 2e-2, worst_act            # SiLU(gate) * up of every active expert (a bf16 ulp at the rounding points)
+    H.assert_close(f"30B-A3B experts (pair={pair_kernel})", got, ref)
+
+
+def test_native_moe_verify_at_30b_a3b_widths():
+    """A 2-layer Qwen3MoeForCausalLM of Qwen3-Coder-30B-A3B's widths (H 2048, 32 q / 4 kv heads, 128 experts of 768,
+    top-8) through NativeTarget.verify vs its own forward (call site model/dflash.py:249-255): routing agreement,
+    logits, taps, K/V on the rows whose routing agrees, ids on margin-screened rows."""
+    _moe_verify_vs_hf(_moe_hf(layers=2, E=128, top_k=8, Ie=768, hidden=2048, heads=32, kv=4, seed=43), (), tap_layers=(0,),
+                      kv_layers=(0, 1), min_same=11)
+
+
 @pytest.mark.parametrize("mlp_only", [(), (1,)])
 def test_native_moe_verify_matches_hf_forward(mlp_only):
     """A Qwen3MoeForCausalLM (16 experts, top-4; optionally a dense layer in between) through NativeTarget.verify vs
     its own forward: router decisions equal on (almost) every row, logits / taps / K/V of the rows whose routing
     agrees within the bf16 tolerance, posterior ids on margin-screened rows."""
+    _moe_verify_vs_hf(_moe_hf(mlp_only=mlp_only), mlp_only, tap_layers=(0, 2), kv_layers=(0, 3), min_same=13)
+
+
+def _moe_verify_vs_hf(hf, mlp_only, tap_layers, kv_layers, min_same):
     from transformers import DynamicCache
     from dflash_amd import NativeTarget
-    hf = _moe_hf(mlp_only=mlp_only)
+    cfg = hf.config
+    L, E, top_k, Hd, V = cfg.num_hidden_layers, cfg.num_experts, cfg.num_experts_per_tok, cfg.hidden_size, cfg.vocab_size
     nt = NativeTarget(hf)
-    assert nt.is_moe and ("gu" in nt.layers[1]) == bool(mlp_only)
+    assert nt.is_moe and all(("gu" in nt.layers[i]) == (i in mlp_only) for i in range(L))
     g = torch.Generator().manual_seed(7)
     P, bs = 50, 16
     prompt = torch.randint(0, 2000, (1, P), generator=g).to(dev())
     block = torch.randint(0, 2000, (1, bs), generator=g).to(dev())
     cache = nt.new_cache(128)
     nt.prefill(prompt, cache)
-    logits = torch.zeros(32, 2048, dtype=BF16, device=dev())
+    logits = torch.zeros(32, V, dtype=BF16, device=dev())
     nt.debug_routing = []
-    post, th = nt.verify(block[0], P, cache, tap_layers=[0, 2], logits_out=logits)
+    post, th = nt.verify(block[0], P, cache, tap_layers=list(tap_layers), logits_out=logits)
     routing = nt.debug_routing
     nt.debug_routing = None
     rc = DynamicCache()
@@ -148,23 +226,23 @@ def test_native_moe_verify_matches_hf_forward(mlp_only):
         hf(prompt, past_key_values=rc, use_cache=True)
         ref = hf(block, position_ids=torch.arange(P, P + bs, device=dev())[None], past_key_values=rc, use_cache=True,
                  output_hidden_states=True, output_router_logits=True)
-    moe_layers = [i for i in range(4) if i not in mlp_only]
+    moe_layers = [i for i in range(L) if i not in mlp_only]
     assert len(routing) == len(moe_layers) == len(ref.router_logits)
     same = torch.ones(bs, dtype=torch.bool)
     for (li, wt), rl in zip(routing, ref.router_logits):
         p = torch.softmax(rl.float(), dim=-1)
-        idx = torch.topk(p, 4, dim=-1).indices.cpu()
-        want = torch.zeros(bs, 16, dtype=torch.bool)
+        idx = torch.topk(p, top_k, dim=-1).indices.cpu()
+        want = torch.zeros(bs, E, dtype=torch.bool)
         want[torch.arange(bs)[:, None], idx] = True
         same &= ((wt[:bs].float().cpu() != 0) == want).all(dim=-1)
-    assert int(same.sum()) >= bs - 3, same          # a near-tie at the k-th place may fall either way in bf16
+    assert int(same.sum()) >= min_same, same          # a near-tie at the k-th place may fall either way in bf16
     rows = same.nonzero()[:, 0].to(dev())
     H.assert_close("MoE verify logits", logits[:bs][rows], ref.logits[0][rows])
     assert torch.equal(post[0], torch.argmax(logits[:bs], dim=-1))
     H.assert_ids_match_where_safe("MoE verify ids", post[0][rows], ref.logits[0][rows])
-    for j, l in enumerate((0, 2)):
-        H.assert_close(f"MoE verify tap {l}", th[:bs, j * 512:(j + 1) * 512][rows], ref.hidden_states[l + 1][0][rows])
-    for li in (0, 3):
+    for j, l in enumerate(tap_layers):
+        H.assert_close(f"MoE verify tap {l}", th[:bs, j * Hd:(j + 1) * Hd][rows], ref.hidden_states[l + 1][0][rows])
+    for li in kv_layers:
         H.assert_close(f"MoE verify K layer {li}", cache.k[li][:, :P + bs][:, torch.cat([torch.arange(P, device=dev()), P + rows])],
                        rc.layers[li].keys[0][:, torch.cat([torch.arange(P, device=dev()), P + rows])], max_rel=H.KV_MAX_REL)
 

@@ -52,7 +52,7 @@ def _verify_vs_hf(name, hf, V, H_, taps, P=70, bs=16, seed=2):
     H.assert_close(f"{name} verify logits", logits[:bs], rl)
     assert torch.equal(post[0], torch.argmax(logits[:bs], dim=-1))
     # random-init weights: a V-way argmax has tiny top-2 margins; the screened rows must agree
-    H.assert_ids_match_where_safe(f"{name} verify ids", post[0], rl, margin_rel=2e-2, min_safe=0)
+    H.assert_ids_match_where_safe(f"{name} verify ids", post[0], rl, margin_rel=2e-2, min_safe=1)
     for j, l in enumerate(taps):
         H.assert_close(f"{name} verify tap layer {l}", th[:bs, j * H_:(j + 1) * H_], ref.hidden_states[l + 1][0])
     L = hf.config.num_hidden_layers
