@@ -65,11 +65,15 @@ struct GemmArgs {
   float *ss_out;  // [ntiles][16] sum over the tile's 16 columns of h_new^2
 };
 
-#ifdef DFL_GEMM_STAMPS  // diagnostic build only (scripts/dbg_gemm_stamps.py): 100 MHz wall stamps of workgroup 0
+#ifdef DFL_GEMM_STAMPS  // diagnostic build only (scripts/dbg_gemm_stamps.py): 100 MHz wall stamps of workgroup 0,
+// and the start / first-item / end stamps of EVERY workgroup (is the tail a few late workgroups or all of them?)
 __device__ unsigned long long g_gstamps[8];
+__device__ unsigned long long g_wgstamps[256][4];
 #define GSTAMP(i)                                                                         \
   do {                                                                                    \
     if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_gstamps[i] = __builtin_amdgcn_s_memrealtime(); \
+    if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 256 && ((i) == 0 || (i) == 4 || (i) == 5))            \
+      g_wgstamps[blockIdx.x][(i) == 0 ? 0 : (i) - 3] = __builtin_amdgcn_s_memrealtime();                           \
   } while (0)
 #else
 #define GSTAMP(i)
@@ -619,6 +623,9 @@ __global__ __launch_bounds__(256) void k_embed_rows(const bf16_t *embed, const i
 #ifdef DFL_GEMM_STAMPS
 extern "C" int dfl_debug_read_gemm_stamps(unsigned long long *host_out) {
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gstamps), sizeof(unsigned long long) * 8);
+}
+extern "C" int dfl_debug_read_wg_stamps(unsigned long long *host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wgstamps), sizeof(unsigned long long) * 256 * 4);
 }
 #endif
 

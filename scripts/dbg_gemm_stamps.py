@@ -31,12 +31,17 @@ normed = ops.rows_normed(h, ss, 256, nw, 1e-6, ops.DYN_BS)
 fragH = ops.rows_frag(torch.randn(16 * H, device=dev).to(BF16))
 fragI = ops.rows_frag(torch.randn(16 * I, device=dev).to(BF16))
 big = torch.empty(600_000_000, dtype=torch.uint8, device=dev)
+def dbg_zero():
+    pass
+
+
 names = ["prologue loads issued", "lengths + rstd", "build x", "first item done", "loop", "tail"]
 
 
 def run(label, fn):
     for rep in range(3):
         big.zero_()
+        dbg_zero()
         torch.cuda.synchronize()
         t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0.record()
@@ -47,6 +52,21 @@ def run(label, fn):
         assert dbg.dfl_debug_read_gemm_stamps(st) == 0
         t = [st[i] for i in range(6)]
         d = [(t[i + 1] - t[i]) / 100.0 for i in range(5)]
+        if rep == 2:
+            wg = (C.c_ulonglong * 1024)()
+            assert dbg.dfl_debug_read_wg_stamps(wg) == 0
+            rows = [(wg[4 * b], wg[4 * b + 1], wg[4 * b + 2]) for b in range(256) if wg[4 * b]]
+            t00 = min(r[0] for r in rows)
+            for name, k in (("start", 0), ("first item done", 1), ("end", 2)):
+                v = sorted((r[k] - t00) / 100.0 for r in rows)
+                print(f"    all {len(rows)} workgroups, {name:16s}: min {v[0]:6.2f}  p10 {v[len(v) // 10]:6.2f}  median {v[len(v) // 2]:6.2f}  "
+                      f"p90 {v[9 * len(v) // 10]:6.2f}  max {v[-1]:6.2f} us after the first start")
+            late = sorted(range(len(rows)), key=lambda b: -rows[b][2])[:12]
+            print("    latest workgroups (block: end us, start us): " + "  ".join(f"{b}: {(rows[b][2] - t00) / 100.0:.1f}, {(rows[b][0] - t00) / 100.0:.2f}" for b in late))
+            byx = [[] for _ in range(8)]
+            for b, r in enumerate(rows):
+                byx[b % 8].append((r[2] - t00) / 100.0)
+            print("    mean end by block % 8: " + "  ".join(f"{sum(v) / len(v):.2f}" for v in byx if v))
         print(f"{label:28s} rep {rep}: first weights asked={(st[6] - st[0]) / 100.0:.2f}  " + "  ".join(f"{n}={x:.2f}" for n, x in zip(names, d)) +
               f"  | wg0 total {(t[5] - t[0]) / 100.0:.2f} us, events {t0.elapsed_time(t1) * 1e3:.1f} us")
 

@@ -192,7 +192,7 @@ def test_native_moe_verify_at_30b_a3b_widths():
     top-8) through NativeTarget.verify vs its own forward (call site model/dflash.py:249-255): routing agreement,
     logits, taps, K/V on the rows whose routing agrees, ids on margin-screened rows."""
     _moe_verify_vs_hf(_moe_hf(layers=2, E=128, top_k=8, Ie=768, hidden=2048, heads=32, kv=4, seed=43), (), tap_layers=(0,),
-                      kv_layers=(0, 1), min_same=11)
+                      kv_layers=(0, 1), min_same=11, fp32_arbiter=True)
 
 
 @pytest.mark.parametrize("mlp_only", [(), (1,)])
@@ -203,7 +203,11 @@ def test_native_moe_verify_matches_hf_forward(mlp_only):
     _moe_verify_vs_hf(_moe_hf(mlp_only=mlp_only), mlp_only, tap_layers=(0, 2), kv_layers=(0, 3), min_same=13)
 
 
-def _moe_verify_vs_hf(hf, mlp_only, tap_layers, kv_layers, min_same):
+def _moe_verify_vs_hf(hf, mlp_only, tap_layers, kv_layers, min_same, fp32_arbiter=False):
+    """fp32_arbiter: with 8 experts per row the HF forward adds the expert outputs one by one INTO A bf16 TENSOR
+    (Qwen3MoeExperts.forward: index_add_), this path sums them in fp32 and rounds once — the two bf16 results then differ
+    by more than two roundings of the same arithmetic.  An fp32 forward of the same weights arbitrates: the native
+    logits must be at least as close to it as HF's own bf16 logits are (and within 6e-2 of those)."""
     from transformers import DynamicCache
     from dflash_amd import NativeTarget
     cfg = hf.config
@@ -236,15 +240,39 @@ def _moe_verify_vs_hf(hf, mlp_only, tap_layers, kv_layers, min_same):
         want[torch.arange(bs)[:, None], idx] = True
         same &= ((wt[:bs].float().cpu() != 0) == want).all(dim=-1)
     assert int(same.sum()) >= min_same, same          # a near-tie at the k-th place may fall either way in bf16
+    if fp32_arbiter:
+        import copy
+        hf32 = copy.deepcopy(hf).float()
+        with torch.inference_mode():
+            rc32 = DynamicCache()
+            hf32(prompt, past_key_values=rc32, use_cache=True)
+            ref32 = hf32(block, position_ids=torch.arange(P, P + bs, device=dev())[None], past_key_values=rc32,
+                         use_cache=True, output_router_logits=True)
+        for (li, wt), rl in zip(routing, ref32.router_logits):      # rows routed alike by all three
+            idx = torch.topk(torch.softmax(rl.float(), dim=-1), top_k, dim=-1).indices.cpu()
+            want = torch.zeros(bs, E, dtype=torch.bool)
+            want[torch.arange(bs)[:, None], idx] = True
+            same &= ((wt[:bs].float().cpu() != 0) == want).all(dim=-1)
+        assert int(same.sum()) >= min_same - 3, same
+        rows = same.nonzero()[:, 0].to(dev())
+        r32 = ref32.logits[0][rows].float()
+        e_nat = (logits[:bs][rows].float() - r32).abs()
+        e_hf = (ref.logits[0][rows].float() - r32).abs()
+        scale = float(r32.abs().max())
+        print(f"[parity] vs fp32 forward: native max {float(e_nat.max()) / scale:.3e} mean {float(e_nat.mean()) / scale:.3e}; "
+              f"HF bf16 max {float(e_hf.max()) / scale:.3e} mean {float(e_hf.mean()) / scale:.3e}")
+        assert float(e_nat.mean()) <= 1.05 * float(e_hf.mean()) and float(e_nat.max()) <= 1.25 * float(e_hf.max())
+        del hf32, rc32, ref32
     rows = same.nonzero()[:, 0].to(dev())
-    H.assert_close("MoE verify logits", logits[:bs][rows], ref.logits[0][rows])
+    H.assert_close("MoE verify logits", logits[:bs][rows], ref.logits[0][rows], max_rel=6e-2 if fp32_arbiter else H.MAX_REL)
     assert torch.equal(post[0], torch.argmax(logits[:bs], dim=-1))
     H.assert_ids_match_where_safe("MoE verify ids", post[0][rows], ref.logits[0][rows])
     for j, l in enumerate(tap_layers):
         H.assert_close(f"MoE verify tap {l}", th[:bs, j * Hd:(j + 1) * Hd][rows], ref.hidden_states[l + 1][0][rows])
     for li in kv_layers:
         H.assert_close(f"MoE verify K layer {li}", cache.k[li][:, :P + bs][:, torch.cat([torch.arange(P, device=dev()), P + rows])],
-                       rc.layers[li].keys[0][:, torch.cat([torch.arange(P, device=dev()), P + rows])], max_rel=H.KV_MAX_REL)
+                       rc.layers[li].keys[0][:, torch.cat([torch.arange(P, device=dev()), P + rows])],
+                       max_rel=4e-2 if fp32_arbiter else H.KV_MAX_REL)   # (behind a top-8 MoE layer: see the docstring)
 
 
 def test_native_moe_target_end_to_end_lossless_walk():
