@@ -73,6 +73,13 @@ SIGNATURES = {
     "dfl_argmax": (_i, [_p, _i, _i, _i64, _p, _p]),
     "dfl_accept_commit": (_i, [_p, _p, _i, _p, _i64, _p, _p, _i, _p, _p]),
     "dfl_accept_commit_rearm": (_i, [_p, _p, _i, _p, _i64, _p, _p, _i, _p, _p, _i, _i64, _p]),
+    # ---- target prefill
+    "dfl_prefill_rows_padded": (_i64, [_i]),
+    "dfl_prefill_gemm_rows": (_i, [_p, _p, _i, _i, _i, _p, _i64, _p]),
+    "dfl_prefill_gemm_resid": (_i, [_p, _p, _i, _i, _i, _p, _i64, _p, _i64, _p]),
+    "dfl_prefill_gemm_silu": (_i, [_p, _p, _i, _i, _i, _p, _p]),
+    "dfl_prefill_norm_pack": (_i, [_p, _i64, _i, _i, _p, _f, _p, _p]),
+    "dfl_prefill_qk_rope": (_i, [_p, _i64, _i, _i, _i, _i, _i, _i, _p, _p, _f, _p, _p, _i, _i, _p, _p, _i, _i, _p]),
     # ---- ragged batch of requests
     "dfl_batch_tiles": (_i, [_i]),
     "dfl_batch_ksplit": (_i, [_i]),

@@ -153,7 +153,7 @@ class BatchedDecoder:
             t.share_lm_head(self.lm_wp)
             self.embed_w = _bf16_table(t.model.embed_tokens.weight, self.dev)
         tc = _View(self.tk[r], self.tv[r], None, self.max_rows)
-        out = t.prefill(input_ids, tc, output_hidden_states=True)
+        out = t.prefill(input_ids, tc, output_hidden_states=True, tap_layers=self.model.target_layer_ids)
         self.output_ids[r].fill_(self.mask_id)
         self.output_ids[r, :P] = input_ids[0]
         first = sample(out.logits, temperature)

@@ -134,7 +134,8 @@ class DecodeSession:
     def prefill(self) -> None:
         """model/dflash.py:218-229."""
         if self.native:
-            out = self.target.prefill(self.input_ids, self.tcache, output_hidden_states=self.use_draft)
+            out = self.target.prefill(self.input_ids, self.tcache, output_hidden_states=self.use_draft,
+                                      tap_layers=self.model.target_layer_ids if self.use_draft else None)
         else:
             out = self.target(self.input_ids, position_ids=self.position_ids[:, :self.n_in],
                               past_key_values=self.tcache, use_cache=True, logits_to_keep=1,

@@ -632,3 +632,46 @@ def accept_commit_batch(block: torch.Tensor, posterior: torch.Tensor, R: int, ou
         _p(dyn_t, I32, "dyn_t"), _p(stop_ids, I64, "stop_ids") if n_stop else None, n_stop,
         _p(result, I32, "result"), block.data_ptr() if rearm_mask_id is not None else None,
         int(rearm_mask_id) if rearm_mask_id is not None else 0, _stream()), "dfl_accept_commit_batch")
+
+
+# ---- target prefill (csrc/prefill.hip)
+def prefill_rows_padded(P: int) -> int:
+    return lib().dfl_prefill_rows_padded(P)
+
+
+def prefill_gemm_rows(wp, x_frag, P: int, N: int, K: int, out: torch.Tensor) -> None:
+    assert out.dtype == BF16 and out.stride(1) == 1 and out.shape[0] >= prefill_rows_padded(P)
+    check(lib().dfl_prefill_gemm_rows(_p(wp, BF16, "wp"), _p(x_frag, BF16, "x_frag"), P, N, K, out.data_ptr(),
+                                      out.stride(0), _stream()), "dfl_prefill_gemm_rows")
+
+
+def prefill_gemm_resid(wp, x_frag, P: int, N: int, K: int, h_io: torch.Tensor, tap=None) -> None:
+    assert h_io.dtype == BF16 and h_io.stride(1) == 1 and h_io.shape[0] >= prefill_rows_padded(P)
+    tp, ldt = None, 0
+    if tap is not None:
+        assert tap.is_cuda and tap.dtype == BF16 and tap.stride(1) == 1 and tap.shape[0] >= P
+        tp, ldt = tap.data_ptr(), tap.stride(0)
+    check(lib().dfl_prefill_gemm_resid(_p(wp, BF16, "wp"), _p(x_frag, BF16, "x_frag"), P, N, K, h_io.data_ptr(),
+                                       h_io.stride(0), tp, ldt, _stream()), "dfl_prefill_gemm_resid")
+
+
+def prefill_gemm_silu(wp_gu, x_frag, P: int, I: int, K: int, act_frag: torch.Tensor) -> None:
+    assert act_frag.numel() >= prefill_rows_padded(P) * I
+    check(lib().dfl_prefill_gemm_silu(_p(wp_gu, BF16, "wp_gu"), _p(x_frag, BF16, "x_frag"), P, I, K,
+                                      _p(act_frag, BF16, "act_frag"), _stream()), "dfl_prefill_gemm_silu")
+
+
+def prefill_norm_pack(h: torch.Tensor, P: int, H: int, norm_w, eps: float, x_frag: torch.Tensor) -> None:
+    assert h.dtype == BF16 and h.stride(1) == 1 and h.shape[0] >= P and x_frag.numel() >= prefill_rows_padded(P) * H
+    check(lib().dfl_prefill_norm_pack(h.data_ptr(), h.stride(0), P, H, _p(norm_w, BF16, "norm_w"), eps,
+                                      _p(x_frag, BF16, "x_frag"), _stream()), "dfl_prefill_norm_pack")
+
+
+def prefill_qk_rope(qkv: torch.Tensor, P: int, q_col: int, k_col: int, v_col: int, n_q: int, n_kv: int, q_norm_w,
+                    k_norm_w, eps: float, cos_tab, sin_tab, pos0: int, kcache, vcache, row0: int) -> None:
+    assert qkv.dtype == BF16 and qkv.stride(1) == 1 and kcache.shape == vcache.shape and kcache.shape[2] == 128
+    check(lib().dfl_prefill_qk_rope(qkv.data_ptr(), qkv.stride(0), P, q_col, k_col, v_col, n_q, n_kv,
+                                    _p(q_norm_w, BF16, "q_norm_w"), _p(k_norm_w, BF16, "k_norm_w"), eps,
+                                    _p(cos_tab, BF16, "cos"), _p(sin_tab, BF16, "sin"), cos_tab.shape[0], pos0,
+                                    _p(kcache, BF16, "kcache"), _p(vcache, BF16, "vcache"), kcache.shape[1], row0,
+                                    _stream()), "dfl_prefill_qk_rope")

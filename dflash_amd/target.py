@@ -18,6 +18,7 @@ loops of this package detect it and take the fast path instead:
 """
 from __future__ import annotations
 
+from types import SimpleNamespace
 from typing import Optional, Sequence
 
 import torch
@@ -49,13 +50,45 @@ class TargetKVCache:
             self.length = max(0, self.length + int(max_length))
 
 
+class _HiddenStates:
+    """hidden_states of a native prefill: indexable like the HF tuple (index 0 = embedding output, l + 1 = output of
+    decoder layer l, model/utils.py:16-25) for the states that were kept."""
+
+    def __init__(self, kept: dict, n: int):
+        self._kept, self._n = kept, n
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        if i < 0:
+            i += self._n
+        if i not in self._kept:
+            raise KeyError(f"hidden state {i} was not kept by this prefill (tap_layers = {sorted(k - 1 for k in self._kept)})")
+        return self._kept[i]
+
+
+class _Weight:
+    """`.weight` holder standing in for the wrapped model's embed_tokens / lm_head once it is gone (keep_hf = False)."""
+
+    def __init__(self, w):
+        self.weight = w
+
+
 class NativeTarget:
-    def __init__(self, hf_model, max_splits: int = 32, attn_impl: str = "head"):
+    def __init__(self, hf_model, max_splits: int = 32, attn_impl: str = "head", keep_hf: bool = True,
+                 prefill: str = "native"):
         """attn_impl: "head" = dfl_attn_head on finished bf16 q/k/v rows (round 2, default); "fused" = the
         round-1 stage (fp32 K-split partials -> dfl_attn_fused), kept for A/B measurement and as a second
-        implementation the tests compare against."""
+        implementation the tests compare against.
+        prefill: "native" (round 3, default where the shapes allow: dense target, projection widths % 128) = the prompt
+        through the MFMA GEMMs of csrc/prefill.hip on the same packed weights; "hf" = through the wrapped model.
+        keep_hf = False: the wrapped model is dropped after packing (ONE copy of the layers' weights in memory; the
+        caller must drop its own reference too); needs the native prefill."""
         if attn_impl not in ("head", "fused"):
             raise ValueError("attn_impl must be 'head' or 'fused'")
+        if prefill not in ("native", "hf"):
+            raise ValueError("prefill must be 'native' or 'hf'")
         self.attn_impl = attn_impl
         # True: attention + o_proj in one launch (dfl_attn_head_oproj) where its range allows.  Measured SLOWER than the
         # two launches (23.2 vs 20.3 us per layer, DESIGN.md section 5): off by default, kept for A/B and tests
@@ -184,6 +217,19 @@ class NativeTarget:
         if self.is_moe:   # MoE layers hand their successor ready-normalised rows (the residual add + norm launch after the experts)
             self.src["xn"] = [ops.rows_frag(ws["xn"][t]) for t in range(NT)]
             self.src["xn1"] = [ops.rows_frag(ws["xn1"][t]) for t in range(NT)]
+        q_dim, kv_dim = self.n_q * 128, self.n_kv * 128
+        self._pf = None
+        self.native_prefill = (prefill == "native" and not self.is_moe and (q_dim + 2 * kv_dim) % 128 == 0
+                               and self.H % 128 == 0 and self.I % 64 == 0 and q_dim % 64 == 0)
+        self._rotary = getattr(hf_model.model, "rotary_emb", None)
+        if not keep_hf:
+            if not self.native_prefill:
+                raise NotImplementedError("NativeTarget(keep_hf=False) needs the native prefill (dense target, widths % 128)")
+            if self.lm_wp is None:
+                self.lm_wp = ops.pack_weight(self.lm_head.weight.detach().to(BF16).contiguous())
+            self.hf = None
+            self.model = SimpleNamespace(embed_tokens=_Weight(self.embed), rotary_emb=self._rotary)
+            self.lm_head = _Weight(self.lm_head.weight.detach())
         self.debug_routing = None
         self.gu_events = None   # (layer, start, end): torch.cuda.Event pair recorded around that layer's gate/up GEMM launch
         self._rope = None
@@ -196,6 +242,8 @@ class NativeTarget:
         return self._dev
 
     def __call__(self, *a, **kw):
+        if self.hf is None:
+            raise RuntimeError("NativeTarget(keep_hf=False): the wrapped model is gone; use prefill() / verify()")
         return self.hf(*a, **kw)
 
     def share_lm_head(self, packed: torch.Tensor) -> None:
@@ -213,17 +261,87 @@ class NativeTarget:
                 self._rope = _rope_tables(128, self.theta, n, self._dev)
             else:  # what the wrapped model itself multiplies by (scaled frequencies, attention factor), in bf16
                 pos = torch.arange(n, device=self._dev).unsqueeze(0)
-                cos, sin = self.model.rotary_emb(torch.zeros(1, dtype=BF16, device=self._dev), pos)
+                cos, sin = self._rotary(torch.zeros(1, dtype=BF16, device=self._dev), pos)
                 self._rope = (cos[0, :, :64].to(BF16).contiguous(), sin[0, :, :64].to(BF16).contiguous())
         return self._rope
 
-    # ---- prefill through the wrapped model, K/V copied into the preallocated cache
+    # ---- prefill (model/dflash.py:218-225)
     @torch.inference_mode()
-    def prefill(self, input_ids: torch.Tensor, cache: TargetKVCache, output_hidden_states: bool = True):
-        from transformers import DynamicCache
+    def prefill(self, input_ids: torch.Tensor, cache: TargetKVCache, output_hidden_states: bool = True,
+                tap_layers: Optional[Sequence[int]] = None):
+        """Returns an object with `.logits` [1, 1, V] (last prompt row, logits_to_keep = 1) and `.hidden_states`
+        (indexable like HF's tuple).  tap_layers: keep only hidden_states[l + 1] for these layers (the draft's taps,
+        model/utils.py:16-25) instead of all of them."""
         P = input_ids.shape[1]
         if P > cache.max_rows:
             raise ValueError("target KV cache too small for the prompt")
+        if self.native_prefill:
+            return self._prefill_native(input_ids, cache, output_hidden_states, tap_layers)
+        return self._prefill_hf(input_ids, cache, output_hidden_states)
+
+    def _prefill_native(self, input_ids, cache, output_hidden_states, tap_layers):
+        """The prompt rows on the kernels: per layer RMSNorm -> frag16 tiles, q/k/v GEMM (bf16 rows), q/k-norm + RoPE +
+        cache write, causal attention over the prompt (torch SDPA on the rows the kernels produced — the one stage of
+        the prefill still outside csrc/: 0.3 of the pass's 14 TFLOP), o_proj + residual, RMSNorm, gate/up + SiLU,
+        down_proj + residual (+ tap).  Last row: final norm + lm_head through the decode path's skinny GEMM."""
+        import torch.nn.functional as F
+        P = input_ids.shape[1]
+        H, I, dev = self.H, self.I, self._dev
+        Pp = ops.prefill_rows_padded(P)
+        q_dim, kv_dim, nqkv = self.q_dim, self.kv_dim, self.nqkv
+        if self._pf is None or self._pf["h"].shape[0] < Pp:
+            z = lambda *s: torch.zeros(*s, dtype=BF16, device=dev)  # noqa: E731
+            self._pf = dict(h=z(Pp, H), xf=z(Pp * max(H, q_dim)), qkv=z(Pp, nqkv), act=z(Pp * I), attn=z(Pp, q_dim),
+                            logits=z(16, self.V), ids=torch.zeros(16, dtype=torch.int64, device=dev))
+        pf = self._pf
+        h, xf, qkv, act, attn = pf["h"], pf["xf"], pf["qkv"], pf["act"], pf["attn"]
+        h.zero_()
+        torch.index_select(self.embed, 0, input_ids[0], out=h[:P])
+        cos, sin = self._rope_tab(P + 64)
+        want = None
+        if output_hidden_states:
+            want = set(range(self.L + 1)) if tap_layers is None else {int(l) + 1 for l in tap_layers}
+            if max(want) >= self.L and tap_layers is not None:
+                raise NotImplementedError("tapping the last layer (post-norm state) is not supported")
+        kept = {}
+        if want and 0 in want:
+            kept[0] = h[:P].clone().unsqueeze(0)
+        for i, lw in enumerate(self.layers):
+            ops.prefill_norm_pack(h, P, H, lw["ln1"], self.eps, xf)
+            ops.prefill_gemm_rows(lw["qkv"], xf, P, nqkv, H, qkv)
+            ops.prefill_qk_rope(qkv, P, 0, q_dim, q_dim + kv_dim, self.n_q, self.n_kv, lw["q_norm"], lw["k_norm"], self.eps,
+                                cos, sin, 0, cache.k[i], cache.v[i], 0)
+            q = qkv[:P, :q_dim].view(P, self.n_q, 128).transpose(0, 1).unsqueeze(0)
+            o = F.scaled_dot_product_attention(q, cache.k[i][:, :P].unsqueeze(0), cache.v[i][:, :P].unsqueeze(0),
+                                               is_causal=True, scale=128 ** -0.5, enable_gqa=self.n_kv != self.n_q)
+            attn[:P].view(P, self.n_q, 128).copy_(o[0].transpose(0, 1))
+            ops.prefill_norm_pack(attn, P, q_dim, None, self.eps, xf)      # rows -> frag16 tiles, no norm
+            ops.prefill_gemm_resid(lw["o"], xf, P, H, q_dim, h)
+            ops.prefill_norm_pack(h, P, H, lw["ln2"], self.eps, xf)
+            ops.prefill_gemm_silu(lw["gu"], xf, P, I, H, act)
+            tap = None
+            if want and (i + 1) in want and i + 1 < self.L:   # (the last layer's output only exists final-normed in HF)
+                tap = torch.empty(P, H, dtype=BF16, device=dev)
+                kept[i + 1] = tap.unsqueeze(0)
+            ops.prefill_gemm_resid(lw["down"], act, P, H, I, h, tap=tap)
+        # last prompt row: final norm + lm_head on its 16-row tile (the decode path's GEMM, norm applied in its prologue)
+        if self.lm_wp is None:
+            self.lm_wp = ops.pack_weight(self.lm_head.weight.detach().to(BF16).contiguous())
+        t0 = (P - 1) // 16 * 16
+        rows = h[t0:t0 + 16]
+        ss = rows.float().pow(2).sum(-1).contiguous()
+        ops.gemm_argmax(self.lm_wp, ops.rows_normed(rows, ss, 1, self.norm, self.eps), self.V, H, 0, 16,
+                        self.ws["argmax_ws"], pf["ids"], 0, logits=pf["logits"])
+        logits = pf["logits"][P - 1 - t0].clone().view(1, 1, self.V)
+        # (hidden_states[L], HF's final-normed state, is not kept: nothing on the path reads it — model/utils.py:16-25
+        # taps layer OUTPUTS, and build_target_layer_ids never picks the last layer)
+        cache.length = P
+        return SimpleNamespace(logits=logits, hidden_states=_HiddenStates(kept, self.L + 1) if output_hidden_states else None)
+
+    def _prefill_hf(self, input_ids, cache, output_hidden_states):
+        """Through the wrapped model, K/V copied into the preallocated cache (MoE targets, odd widths, prefill="hf")."""
+        from transformers import DynamicCache
+        P = input_ids.shape[1]
         tmp = DynamicCache()
         pos = torch.arange(P, device=self._dev).unsqueeze(0)
         out = self.hf(input_ids, position_ids=pos, past_key_values=tmp, use_cache=True, logits_to_keep=1,

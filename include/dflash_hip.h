@@ -347,6 +347,40 @@ int dfl_accept_commit_rearm(const int64_t *block_ids, const int64_t *posterior, 
                             int64_t *next_block, int rearm_n, int64_t mask_id, void *stream);
 
 /* ======================================================================================
+ * Target PREFILL on the kernels (model/dflash.py:218-225: target(input_ids, ..., output_hidden_states=True) over the
+ * P prompt rows).  Same operands as the decode path: weights as packed by dfl_pack_weight /
+ * dfl_pack_weight_gateup, activations as frag16 row tiles — tile t (rows 16t .. 16t+15) of K columns at
+ * x_frag + t * 16 * K elements, dfl_prefill_rows_padded(P) / 16 tiles (rows are padded to a multiple of 128; the
+ * padding holds zero fragments).  LDS-tiled MFMA GEMM (128 x 128 block tiles, LDS-DMA staging).  N % 128 == 0,
+ * K % 64 == 0.  Row buffers must hold dfl_prefill_rows_padded(P) rows; rows >= P are never stored.
+ * ====================================================================================== */
+int64_t dfl_prefill_rows_padded(int P);
+
+/* out[m][n] = bf16(x[m] . W[n])  (bf16 rows, row stride ldo): the q/k/v projection of the prompt rows. */
+int dfl_prefill_gemm_rows(const void *wp, const void *x_frag, int P, int N, int K, void *out, int64_t ldo, void *stream);
+
+/* h_io[m][n] = bf16(h_io[m][n] + bf16(x[m] . W[n])) (o_proj / down_proj + residual add); tap (optional) gets a copy
+ * of the new rows (row stride ldtap): a tapped target layer, model/utils.py:16-25. */
+int dfl_prefill_gemm_resid(const void *wp, const void *x_frag, int P, int N, int K, void *h_io, int64_t ldh, void *tap,
+                           int64_t ldtap, void *stream);
+
+/* act = bf16(silu(gate) * up) over the interleaved gate/up weight (tf:modeling_qwen3.py:82), written as frag16 row
+ * tiles of I columns (the down projection's input).  I % 64 == 0. */
+int dfl_prefill_gemm_silu(const void *wp_gateup, const void *x_frag, int P, int I, int K, void *act_frag, void *stream);
+
+/* Rows h [P][H] (bf16, row stride ldh) -> Qwen3RMSNorm (tf:modeling_qwen3.py:59-64; norm_w NULL: none) -> frag16 row
+ * tiles of H columns; all dfl_prefill_rows_padded(P) / 16 tiles are written (zero fragments beyond row P). */
+int dfl_prefill_norm_pack(const void *h, int64_t ldh, int P, int H, const void *norm_w, float eps, void *x_frag,
+                          void *stream);
+
+/* Per-head q/k RMSNorm (weights may be NULL: Llama) + RoPE at positions pos0 + row over the P rows of a bf16 q/k/v row
+ * buffer (row stride ld): q is rewritten in place, k (normed, rotated) and v go to cache rows row0 + row of
+ * kcache / vcache [n_kv][cache_rows][128].  cos/sin: bf16 [max_pos][64]. */
+int dfl_prefill_qk_rope(void *qkv_rows, int64_t ld, int P, int q_col, int k_col, int v_col, int n_q, int n_kv,
+                        const void *q_norm_w, const void *k_norm_w, float eps, const void *cos_tab, const void *sin_tab,
+                        int max_pos, int pos0, void *kcache, void *vcache, int cache_rows, int row0, void *stream);
+
+/* ======================================================================================
  * Ragged batch of requests on one GPU (BASELINE.json configs[2]; SURVEY.md §8e: "within a
  * GPU the requests are a ragged batch for the kernels: shared weight stream, per-request
  * S and tau").  The reference has no batched form of the path — "batch" there is a Python
