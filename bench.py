@@ -106,7 +106,10 @@ def gpu_leg(args, rank, world, dev):
     target, perm = make_hf_target(dev, layers=args.target_layers)
     if not args.hf_verify:
         from dflash_amd import NativeTarget
-        target = NativeTarget(target, attn_impl=args.attn_impl)   # verify on the kernels, prefill through HF
+        # verify AND prefill on the kernels; the wrapped HF model is dropped after packing (one copy of
+        # the target's weights in memory) unless --hf-prefill asks for the round-2 configuration
+        target = NativeTarget(target, attn_impl=args.attn_impl, keep_hf=args.hf_prefill,
+                              prefill="hf" if args.hf_prefill else "native")
         target.fuse_oproj = args.fuse_oproj
     cfg = DFlashConfig(**{**QWEN3_8B_DRAFT, "num_target_layers": args.target_layers})
     draft = DFlashDraftModel(cfg, device=dev)
@@ -167,8 +170,10 @@ def gpu_leg(args, rank, world, dev):
         s.cycle(bs)                  # cycle 0: carries the one-off 1024-row draft-context prefill
         torch.cuda.synchronize()
         ttft_side = {"target_prefill_ms": 1e3 * (t_c0 - t_pf), "cycle0_ms": 1e3 * (time.perf_counter() - t_c0),
-                     "note": "second request on warm code (outside the timed region): the target prefill runs through the "
-                             f"wrapped HF model; cycle 0 = projection of the {P} prompt context rows into the draft cache "
+                     "note": "second request on warm code (outside the timed region): the target prefill runs "
+                             + ("through the wrapped HF model" if (args.hf_verify or args.hf_prefill) else
+                                "on the kernels (csrc/prefill.hip: MFMA GEMMs on the packed weights; attention core torch SDPA)")
+                             + f"; cycle 0 = projection of the {P} prompt context rows into the draft cache "
                              "(model/dflash.py:73-85, 64 rows per pass) + one decode cycle"}
     s.cycle(bs)                      # first steady-state cycle: one-off code-object loads (60 ms) — setup, like cycle 0
     for _ in range(args.warmup):
@@ -502,6 +507,8 @@ def main():
     ap.add_argument("--hf-verify", action="store_true",
                     help="verify through the HF/PyTorch target forward (round-1 configuration) instead of "
                          "dflash_amd.NativeTarget")
+    ap.add_argument("--hf-prefill", action="store_true",
+                    help="A/B: target prefill through the wrapped HF model (round-2 configuration; keeps both weight copies)")
     ap.add_argument("--fuse-oproj", action="store_true",
                     help="A/B: attention stage and o_proj as ONE launch (dfl_attn_head_oproj; measured slower, off by default)")
     ap.add_argument("--attn-impl", choices=["head", "fused"], default="head",
@@ -558,7 +565,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "Qwen3-8B-shaped target (" + ("HF/PyTorch-ROCm verify" if args.hf_verify else
-                                   "HF prefill, NativeTarget verify on the kernels") + ") + DFlash-b16 5-layer draft, "
+                                   ("HF prefill, " if args.hf_prefill else "NativeTarget prefill and ") + "verify on the kernels") + ") + DFlash-b16 5-layer draft, "
                                    f"block=16, temp=0, batch={args.requests_per_gpu} per GPU, prefix={args.prefix}, random-init weights, "
                                    "scripted acceptance (seeded truncated-geometric, mean tau 7.3 over the timed cycles)",
                        "target_layers": args.target_layers, "requests": world * args.requests_per_gpu,

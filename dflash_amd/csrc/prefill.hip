@@ -34,13 +34,17 @@ struct PGemmArgs {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
-template <int EPI>
+// MW = row tiles per wave: 4 -> block tile 128 columns x 128 rows; 2 -> 128 x 64 (twice the workgroups: the N = 4096
+// projections o_proj / down_proj have only 32 column blocks, and ONE 4-wave workgroup per CU leaves the matrix pipe idle
+// whenever it waits for its own LDS-DMA: 115 -> see DESIGN.md for the measured step)
+template <int EPI, int MW>
 __global__ __launch_bounds__(256) void k_pgemm(PGemmArgs a) {
-  __shared__ bf16x8 lds[2][32][64];  // [stage][slot: 0..15 = W (n tile, k-step), 16..31 = X (m tile, k-step)][lane]
+  constexpr int MB = 2 * MW;  // row tiles per block
+  __shared__ bf16x8 lds[2][16 + 2 * MB][64];  // [stage][slot: 0..15 = W (n tile, k-step), 16.. = X (m tile, k-step)][lane]
   const int tid = threadIdx.x;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l = tid & 63;
-  const int nbx = a.ntiles >> 3, nby = a.mtiles >> 3;
+  const int nbx = a.ntiles >> 3, nby = a.mtiles / MB;
   // column block / row block of this workgroup: the nby row blocks of a column block are 8 apart in blockIdx
   int nb, mb;
   {
@@ -58,22 +62,23 @@ __global__ __launch_bounds__(256) void k_pgemm(PGemmArgs a) {
   const int wn = w & 1, wm = w >> 1;  // the wave's 64 columns x 64 rows inside the block tile
   const int KT = a.KS >> 1;           // 64-deep steps
 
-  // stage kt -> buffer: waves 0, 1 fetch the 16 weight fragments, waves 2, 3 the 16 activation fragments
+  // stage kt -> buffer: 16 weight fragments + 2 MB activation fragments of 1 KiB, dealt round-robin to the 4 waves
   auto stage = [&](int kt, int buf) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int s16 = (w & 1) * 8 + i;  // fragment 0..15 of this operand: (tile s16 >> 1, k-step s16 & 1)
-      const bf16x8 *src = (w < 2 ? a.wp + ((size_t)(nb * 8 + (s16 >> 1)) * a.KS + kt * 2 + (s16 & 1)) * 64
-                                 : a.xf + ((size_t)(mb * 8 + (s16 >> 1)) * a.KS + kt * 2 + (s16 & 1)) * 64) + l;
-      __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)&lds[buf][(w < 2 ? 0 : 16) + s16][0], 16, 0, 0);
+    for (int i = 0; i < (16 + 2 * MB) / 4; ++i) {
+      const int slot = i * 4 + w;  // wave-uniform
+      const int s16 = slot < 16 ? slot : slot - 16;  // fragment of its operand: (tile s16 >> 1, k-step s16 & 1)
+      const bf16x8 *src = (slot < 16 ? a.wp + ((size_t)(nb * 8 + (s16 >> 1)) * a.KS + kt * 2 + (s16 & 1)) * 64
+                                     : a.xf + ((size_t)(mb * MB + (s16 >> 1)) * a.KS + kt * 2 + (s16 & 1)) * 64) + l;
+      __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)&lds[buf][slot][0], 16, 0, 0);
     }
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[4][MW];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < MW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   stage(0, 0);
   for (int kt = 0; kt < KT; ++kt) {
@@ -83,23 +88,23 @@ __global__ __launch_bounds__(256) void k_pgemm(PGemmArgs a) {
     if (kt + 1 < KT) stage(kt + 1, buf ^ 1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 af[4], bq[4];
+      bf16x8 af[4], bq[MW];
 #pragma unroll
       for (int i = 0; i < 4; ++i) af[i] = lds[buf][(wn * 4 + i) * 2 + ks][l];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bq[j] = lds[buf][16 + (wm * 4 + j) * 2 + ks][l];
+      for (int j = 0; j < MW; ++j) bq[j] = lds[buf][16 + (wm * MW + j) * 2 + ks][l];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bq[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < MW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bq[j], acc[i][j], 0, 0, 0);
     }
   }
 
   // D layout (A = W rows n, B = x^T columns m): lane L, register r = column 4 (L >> 4) + r of the n tile, row L & 15
   const int fm = l & 15, fg = l >> 4;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int mt = mb * 8 + wm * 4 + j;
+  for (int j = 0; j < MW; ++j) {
+    const int mt = mb * MB + wm * MW + j;
     const int m = mt * 16 + fm;
     if (EPI == PEPI_SILU) {
 #pragma unroll
@@ -139,40 +144,43 @@ __global__ __launch_bounds__(256) void k_pgemm(PGemmArgs a) {
   }
 }
 
-// rows [P][H] -> (RMSNorm) -> frag16 row tiles.  One workgroup per 16-row tile, 16 threads per row.
-// norm_w == nullptr: pack only.  Rows >= P give zero fragments.
+// rows [P][H] -> (RMSNorm) -> frag16 row tiles.  One WAVE per row (grid = row tiles x 4, four rows per workgroup): the
+// row's chunks stay in registers between the sum of squares and the normalisation (one pass over memory; the first
+// form, one workgroup per 16-row tile with 16 threads per row, took 22 us for 1024 x 4096: 64 workgroups, two passes).
+// norm_w == nullptr: pack only.  Rows >= P give zero fragments.  H <= 64 * 8 * PN_MAXC.
+constexpr int PN_MAXC = 8;
 __global__ __launch_bounds__(256) void k_pnorm_pack(const bf16_t *h, int64_t ldh, int P, int H, const bf16_t *norm_w,
                                                     float eps, bf16x8 *xf) {
-  const int mt = blockIdx.x, tid = threadIdx.x;
-  const int m = tid >> 4, part = tid & 15;
+  const int mt = blockIdx.x, l = threadIdx.x & 63;
+  const int m = blockIdx.y * 4 + (threadIdx.x >> 6);
   const int row = mt * 16 + m;
   const int KS = H >> 5, nch = H >> 3;
   const bf16_t *src = h + (int64_t)row * ldh;
-  float rstd = 1.f;
-  if (norm_w) {
-    float ss = 0.f;
-    if (row < P)
-      for (int c = part; c < nch; c += 16) {
-        const bf16x8 v = *reinterpret_cast<const bf16x8 *>(src + c * 8);
+  bf16x8 v[PN_MAXC];
+  float ss = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ss += bf2f(v[j]) * bf2f(v[j]);
-      }
-    ss = row_sum16(ss);  // the 16 threads of a row are one DPP row
-    rstd = rsqrtf(ss / (float)H + eps);
+  for (int i = 0; i < PN_MAXC; ++i) {
+    const int c = l + 64 * i;
+    v[i] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    if (row < P && c < nch) v[i] = *reinterpret_cast<const bf16x8 *>(src + c * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ss += bf2f(v[i][j]) * bf2f(v[i][j]);
   }
+  float rstd = 1.f;
+  if (norm_w) rstd = rsqrtf(wave_sum(ss) / (float)H + eps);
   bf16x8 *dst = xf + (size_t)mt * KS * 64;
-  for (int c = part; c < nch; c += 16) {
-    bf16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (row < P) {
-      const bf16x8 v = *reinterpret_cast<const bf16x8 *>(src + c * 8);
-      o = v;
+#pragma unroll
+  for (int i = 0; i < PN_MAXC; ++i) {
+    const int c = l + 64 * i;
+    if (c < nch) {
+      bf16x8 o = v[i];
       if (norm_w) {  // Qwen3RMSNorm: weight * bf16(x * rstd), tf:modeling_qwen3.py:59-64
         const bf16x8 wv = *reinterpret_cast<const bf16x8 *>(norm_w + c * 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(wv[j]) * rbf(bf2f(v[j]) * rstd));
+        for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(wv[j]) * rbf(bf2f(v[i][j]) * rstd));
       }
+      dst[(size_t)c * 16 + m] = o;  // chunk c = k-step c >> 2, lane (c & 3) * 16 + m
     }
-    dst[(size_t)c * 16 + m] = o;  // chunk c = k-step c >> 2, lane (c & 3) * 16 + m
   }
 }
 
@@ -254,7 +262,11 @@ bool pgemm_fill(PGemmArgs &a, const void *wp, const void *xf, int P, int N, int 
 
 template <int EPI>
 void pgemm_launch(const PGemmArgs &a, hipStream_t st) {
-  hipLaunchKernelGGL((k_pgemm<EPI>), dim3((a.ntiles / 8) * (a.mtiles / 8)), dim3(256), 0, st, a);
+  // 128-row blocks unless that leaves fewer than two workgroups per CU
+  if ((a.ntiles / 8) * (a.mtiles / 8) >= 512)
+    hipLaunchKernelGGL((k_pgemm<EPI, 4>), dim3((a.ntiles / 8) * (a.mtiles / 8)), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((k_pgemm<EPI, 2>), dim3((a.ntiles / 8) * (a.mtiles / 4)), dim3(256), 0, st, a);
 }
 
 }  // namespace
@@ -301,9 +313,10 @@ extern "C" int dfl_prefill_gemm_silu(const void *wp_gateup, const void *x_frag, 
 
 extern "C" int dfl_prefill_norm_pack(const void *h, int64_t ldh, int P, int H, const void *norm_w, float eps,
                                      void *x_frag, void *stream) {
-  DFL_REQUIRE(h && x_frag && P >= 1 && H > 0 && H % 32 == 0 && ldh >= H && ldh % 8 == 0, "dfl_prefill_norm_pack: bad shape");
+  DFL_REQUIRE(h && x_frag && P >= 1 && H > 0 && H % 32 == 0 && H <= 64 * 8 * PN_MAXC && ldh >= H && ldh % 8 == 0,
+              "dfl_prefill_norm_pack: bad shape (H %% 32, H <= %d)", 64 * 8 * PN_MAXC);
   const int mtiles = (P + 127) / 128 * 8;  // the padded row tiles are written too (zero fragments)
-  hipLaunchKernelGGL(k_pnorm_pack, dim3(mtiles), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)h, ldh, P, H,
+  hipLaunchKernelGGL(k_pnorm_pack, dim3(mtiles, 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)h, ldh, P, H,
                      (const bf16_t *)norm_w, eps, (bf16x8 *)x_frag);
   DFL_CHECK_LAUNCH("dfl_prefill_norm_pack");
   return DFL_OK;
