@@ -456,3 +456,104 @@ def dflash_generate_batch(model: DFlashDraftModel, target: NativeTarget, input_i
                                          acceptance_lengths=taus[r], cycle_trace=[], profile_summary=None)
         del dec
     return results
+
+
+@torch.inference_mode()
+def dflash_generate_policy_batch(*, model: DFlashDraftModel, target: NativeTarget, input_ids: Sequence[torch.Tensor],
+                                 mask_token_id: int, max_new_tokens: int, stop_token_ids, temperature: float,
+                                 schedulers: Sequence, draft_token_hook: Optional[Callable] = None,
+                                 group_size: int = MAX_GROUP) -> list:
+    """`dflash_generate_policy` (benchmark_dynamic_schedule.py:260-434) for a list of prompts, the requests of a group
+    sharing the weight stream: every request has its OWN scheduler (schedulers[i], e.g. an EWMAPerformanceScheduler) and
+    therefore its own block size per cycle — the kernels read each request's size from its length record, so a group
+    may mix 8-, 12- and 16-row blocks in one pass over the weights.  Returns one namespace per prompt with the fields of
+    :425-434.  The cycle time a scheduler is fed is the GROUP's cycle wall time (what its request actually waited).
+    Block sizes <= 16 (one tile per request); T = 0 (the reference samples the draft with T too, :342 — a per-request
+    RNG stream over a shared launch has no counterpart in it): both raise NotImplementedError otherwise."""
+    if temperature >= 1e-5:
+        raise NotImplementedError("the batched policy loop is greedy; run T > 0 requests through dflash_generate_policy")
+    n = len(input_ids)
+    if len(schedulers) != n:
+        raise ValueError("one scheduler per prompt")
+    for sc in schedulers:
+        if max(sc.candidates) > 16:
+            raise NotImplementedError("the batched kernels take blocks of at most 16 rows")
+    results = [None] * n
+    stop_t = None
+    for g0 in range(0, n, group_size):
+        idx = list(range(g0, min(n, g0 + group_size)))
+        prompts = [input_ids[i] for i in idx]
+        scheds = [schedulers[i] for i in idx]
+        pmax = max(p.shape[1] for p in prompts)
+        max_len = [p.shape[1] + max_new_tokens for p in prompts]
+        dec = BatchedDecoder(model, target, len(idx), max_rows=pmax + max_new_tokens + 3 * 16,
+                             out_len=pmax + max_new_tokens + 16, mask_token_id=mask_token_id,
+                             stop_token_ids=stop_token_ids, temperature=0.0)
+        stop_t = dec.stop_t
+        t0 = cuda_time()
+        for r, p in enumerate(prompts):
+            dec.admit(r, p, 0.0)
+        ttft = cuda_time() - t0
+        R = len(idx)
+        taus, used, traces, cyc = [[] for _ in idx], [[] for _ in idx], [[] for _ in idx], [0] * R
+        hook = (lambda r, blk, start, call: draft_token_hook(idx[r], blk, start, call)) if draft_token_hook else None
+        stop_always = stop_token_ids is not None and mask_token_id in stop_token_ids
+        for r in range(R):
+            if dec.start[r] >= max_len[r]:
+                dec.park(r)
+        t1 = cuda_time()
+        clock = [t1]
+        first = True
+        while any(dec.live):
+            chosen, bs, lgen, start_idx = [0] * R, [0] * R, [0.0] * R, list(dec.start)
+            for r in range(R):
+                if dec.live[r]:
+                    chosen[r] = scheds[r].select(cyc[r])
+                    bs[r] = max(1, min(chosen[r], max_len[r] - dec.start[r]))
+                    dec.set_block_size(r, bs[r])
+                    lgen[r] = float(bs[r])
+
+            def after_draft(first_now=first):
+                # EOS-aware generated length (benchmark_dynamic_schedule.py:344-349)
+                if stop_t is not None:
+                    for r in range(R):
+                        if dec.live[r] and bs[r] > 1:
+                            pos = torch.isin(dec.block[r, 1:bs[r]], stop_t).nonzero(as_tuple=True)[0]
+                            if pos.numel() > 0:
+                                lgen[r] = float(min(int(pos[0].item()) + 1, bs[r]))
+                if first_now:   # the TPOT clock restarts after the first draft (benchmark_dynamic_schedule.py:352-354)
+                    clock[0] = cuda_time()
+
+            c0 = cuda_time()
+            out = dec.cycle(hook, after_draft=after_draft)
+            cycle_s = cuda_time() - c0
+            if first:
+                first, t1 = False, clock[0]
+            for r, o in enumerate(out):
+                if o is None:
+                    continue
+                sc = scheds[r]
+                tau = o[0]
+                taus[r].append(tau)
+                used[r].append(bs[r])
+                sc.update(tau=tau, cycle_s=cycle_s, effective_bs=bs[r], cycle_idx=cyc[r], l_gen=lgen[r])
+                traces[r].append({
+                    "cycle_idx": cyc[r], "start_idx": int(start_idx[r]), "block_size": int(bs[r]),
+                    "chosen_block_size": int(chosen[r]), "tau": int(tau), "l_gen": float(lgen[r]),
+                    "acceptance_ratio": float(tau / max(1, bs[r])), "cycle_s": float(cycle_s),
+                    "tau_hat": sc.tau_hat.get(bs[r]), "cycle_hat": sc.cycle_hat.get(bs[r]),
+                    "score_hat": sc.score_hat.get(bs[r]), "current_block_size": int(sc.current),
+                    "adl_lgen_hat": sc.adl_lgen_hat, "adl_lacc_hat": sc.adl_lacc_hat,
+                    "adl_target_k": int(sc.adl_target_k), "adl_target_bs": int(sc.adl_target_bs)})
+                cyc[r] += 1
+                if o[1] or stop_always or dec.start[r] >= max_len[r]:
+                    dec.park(r)
+        decode_s = cuda_time() - t1
+        for r, i in enumerate(idx):
+            ids = _trim(dec.output_ids[r:r + 1], max_len[r], mask_token_id, stop_token_ids, dec.n_in[r])
+            n_out = ids.shape[1] - dec.n_in[r]
+            results[i] = SimpleNamespace(output_ids=ids.clone(), num_input_tokens=dec.n_in[r], num_output_tokens=n_out,
+                                         time_to_first_token=ttft, time_per_output_token=decode_s / max(1, n_out),
+                                         acceptance_lengths=taus[r], used_block_sizes=used[r], cycle_trace=traces[r])
+        del dec
+    return results

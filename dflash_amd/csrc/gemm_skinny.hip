@@ -185,25 +185,23 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &a) {
   float gate_sum = 0.f;    // SILU: the pair's gate sum, kept across one position
   int arg_rows = 0;
 
-  // chunked kernels: item (tile t, chunk c) = the wave's weights of that chunk AND its activation fragments
+  // chunked kernels: item (tile t, chunk c) = the wave's weights of that chunk AND its activation fragments.  Only the
+  // REQUESTS are made here; the mask (rows beyond the valid count, k-steps beyond K) is applied in process(), right in
+  // front of the MFMAs.  Round 2 masked right behind the requests: a wait for the activation loads — which return after
+  // the weights requested in front of them — so every wave waited for the item it had JUST asked for and no two items
+  // of a wave were ever in flight (down_proj at 4.9 TB/s, its workgroups ending 3.4 us apart).
   auto load_item_x = [&](bf16x8(&xb)[MT][FR], int c) {
     const int ks0 = ks0_of(c);
     int ks[FR];
-    bool take[FR];
 #pragma unroll
-    for (int f = 0; f < FR; ++f) {
-      take[f] = ks0 + f < a.KS;
-      ks[f] = take[f] ? ks0 + f : a.KS - 1;
-    }
-    bf16x8 raw[MT][FR], wv[MT][FR];
+    for (int f = 0; f < FR; ++f) ks[f] = ks0 + f < a.KS ? ks0 + f : a.KS - 1;
+    bf16x8 wv[MT][FR];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int f = 0; f < FR; ++f) wv[mt][f] = raw[mt][f] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      for (int f = 0; f < FR; ++f) wv[mt][f] = xb[mt][f] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) issue_x<FR, false>(a.src[mt], ks, l, nv[mt], raw[mt], wv[mt]);  // no mode 2 here
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) finish_x<FR, false>(a.src[mt], take, l, nv[mt], 1.f, raw[mt], wv[mt], xb[mt]);
+    for (int mt = 0; mt < MT; ++mt) issue_x<FR, false>(a.src[mt], ks, l, nv[mt], xb[mt], wv[mt]);  // no mode 2 here
   };
   auto load_item = [&](bf16x8(&wr)[FR], bf16x8(&xb)[MT][FR], int t, int c, int half) {
     load_ksteps<FR>(wr, a.wp + ((size_t)t * a.KS + ks0_of(c)) * 64, nf_of(c), l, half);
@@ -281,11 +279,18 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &a) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+    const int ks0c = ks0_of(c);
 #pragma unroll
     for (int f = 0; f < FR; ++f)  // k-steps past the wave's share carry zero weights AND zero activations
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[f], CHUNKED ? xb[mt][f] : xr[mt][f], acc[mt], 0, 0, 0);
+      for (int mt = 0; mt < MT; ++mt) {
+        bf16x8 xv = xr[mt][f];
+        if (CHUNKED) {
+          const bool keep = ks0c + f < a.KS && (a.src[mt].mode == 0 || (l & 15) < nv[mt]);
+          xv = keep ? xb[mt][f] : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        }
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[f], xv, acc[mt], 0, 0, 0);
+      }
     if (!CHUNKED || c == a.nch - 1) finish(t, pos);
   };
 
@@ -481,6 +486,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &a) {
         ++jn;
       }
       // (the single-chunk kernels requested item 1 in the prologue)
+      // (requesting unconditionally — a zero-length dummy past the last item, so that hipcc can count the loads in
+      // flight — was tried twice in this 16-wave kernel, rounds 2 and 3: 20.4 -> 20.8 us on down_proj; not kept)
       if (i + 1 < nitems && (CHUNKED || moe || !DFL_EARLY_B || i > 0)) load_item(wB, xB, tile_of(jn), cn, half_of(jn));
       process(wA, xA, tile_of(j), c, j);
       if (i == 0) GSTAMP(4);

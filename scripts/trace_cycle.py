@@ -11,7 +11,7 @@ import os
 rows = list(csv.DictReader(open(max(glob.glob(d + '/*kernel_trace.csv'), key=os.path.getmtime))))
 mine = [r for r in rows if '(anonymous namespace)::k_' in r['Kernel_Name'] and 'at::native' not in r['Kernel_Name']]
 rs = sorted(mine, key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rs) if 'k_gemm<1, false, 2>' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rs) if 'k_gemm<1, false, 2' in r['Kernel_Name']]
 
 
 def nm(r):

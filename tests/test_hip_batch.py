@@ -439,3 +439,83 @@ def test_batch_with_llama_style_target():
     for i in range(3):
         assert outs[i].output_ids[0].tolist() == singles[i].output_ids[0].tolist() == Gs[i][:lens[i] + n_new].tolist(), i
         assert outs[i].acceptance_lengths == singles[i].acceptance_lengths
+
+
+def _ewma(cands):
+    from dflash_amd import EWMAPerformanceScheduler
+    return EWMAPerformanceScheduler(candidates=list(cands), scheduler_mode="ewma", warmup_cycles=3, ewma_alpha=0.25,
+                                    switch_margin=0.03, required_streak=2, cooldown_cycles=2, probe_interval=5,
+                                    low_accept_threshold=0.2, low_accept_streak=3, adl_rho=0.3, adl_delta=1.0,
+                                    adl_k_min=min(cands), adl_k_max=max(cands), adl_neighborhood=4)
+
+
+def test_batched_policy_loop_one_scheduler_per_request():
+    """dflash_generate_policy_batch (benchmark_dynamic_schedule.py:260-434, one EWMA scheduler per request): a group mixes
+    8-, 12- and 16-row blocks in ONE pass over the weights.  Scheduler decisions depend on measured cycle times, so the
+    check is what every schedule must satisfy: committed ids are the target's greedy walk, each cycle's block size is a
+    candidate of that request's scheduler (or the clamped tail), acceptance lengths fit the blocks and add up, trace
+    rows carry the reference's fields; a fixed schedule reproduces the single-request loop exactly."""
+    from dflash_amd import dflash_generate_policy
+    from dflash_amd.batch import dflash_generate_policy_batch
+    from dflash_amd.synthetic import greedy_walk
+    cfg, m, hf, nt, perm = _setup()
+    lens, n_new = (33, 18, 50), 80
+    prompts = [torch.randint(0, 2000, (1, P), generator=torch.Generator().manual_seed(90 + i)).to(dev())
+               for i, P in enumerate(lens)]
+    Gs = [greedy_walk(perm, p, n_new + 40).to(dev()) for p in prompts]
+    plans = [H.make_plan(96, 16, 31 + i) for i in range(len(lens))]
+
+    def bhook(i, blk, start, call):
+        bs_now = min(16, lens[i] + n_new - start)
+        k = min(plans[i][call], bs_now - 1)
+        blk[0, 1:k + 1] = Gs[i][start + 1:start + k + 1]
+        if k + 1 < 16:
+            w = Gs[i][start + k + 1]
+            blk[0, k + 1] = torch.where(blk[0, k + 1] == w, (w + 1) % 2000, blk[0, k + 1])
+
+    cands = [(8, 12, 16), (8, 16), (12, 16)]
+    outs = dflash_generate_policy_batch(model=m, target=nt, input_ids=prompts, mask_token_id=cfg.mask_token_id,
+                                        max_new_tokens=n_new, stop_token_ids=None, temperature=0.0,
+                                        schedulers=[_ewma(c) for c in cands], draft_token_hook=bhook)
+    mixed = set()
+    for i, o in enumerate(outs):
+        assert o.output_ids[0].tolist() == Gs[i][:lens[i] + n_new].tolist(), f"request {i}"
+        assert o.num_output_tokens == n_new and sum(o.acceptance_lengths) == n_new
+        assert len(o.used_block_sizes) == len(o.acceptance_lengths) == len(o.cycle_trace) > 4
+        for row, bs, tau in zip(o.cycle_trace, o.used_block_sizes, o.acceptance_lengths):
+            assert row["chosen_block_size"] in cands[i] and bs == min(row["chosen_block_size"], lens[i] + n_new - row["start_idx"])
+            assert 1 <= tau <= bs and row["tau"] == tau and row["cycle_s"] > 0
+        mixed.update(o.used_block_sizes)
+    assert len(mixed) >= 2            # the group really ran blocks of different sizes together
+
+    class Fixed:                      # a schedule that does not depend on timing: 12-row blocks throughout
+        candidates = (12,)
+        tau_hat = cycle_hat = score_hat = {}
+        adl_lgen_hat = adl_lacc_hat = None
+        current = adl_target_k = adl_target_bs = 12
+
+        def select(self, cyc):
+            return 12
+
+        def update(self, **_):
+            pass
+
+    outs12 = dflash_generate_policy_batch(model=m, target=nt, input_ids=prompts, mask_token_id=cfg.mask_token_id,
+                                          max_new_tokens=n_new, stop_token_ids=None, temperature=0.0,
+                                          schedulers=[Fixed() for _ in lens], draft_token_hook=bhook)
+    for i, o in enumerate(outs12):
+        def shook(blk, start, call, i=i):
+            k = min(plans[i][call], blk.shape[1] - 1)
+            blk[0, 1:k + 1] = Gs[i][start + 1:start + k + 1]
+            if k + 1 < blk.shape[1]:
+                w = Gs[i][start + k + 1]
+                blk[0, k + 1] = torch.where(blk[0, k + 1] == w, (w + 1) % 2000, blk[0, k + 1])
+        ref = dflash_generate_policy(model=m, target=nt, input_ids=prompts[i], mask_token_id=cfg.mask_token_id,
+                                     max_new_tokens=n_new, stop_token_ids=None, temperature=0.0, fixed_block_size=12,
+                                     draft_token_hook=shook)
+        assert o.output_ids[0].tolist() == ref.output_ids[0].tolist()
+        assert o.acceptance_lengths == ref.acceptance_lengths and o.used_block_sizes == ref.used_block_sizes
+    with pytest.raises(NotImplementedError):
+        dflash_generate_policy_batch(model=m, target=nt, input_ids=prompts, mask_token_id=cfg.mask_token_id,
+                                     max_new_tokens=8, stop_token_ids=None, temperature=0.7,
+                                     schedulers=[_ewma((8, 16)) for _ in lens])
