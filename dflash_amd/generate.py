@@ -118,6 +118,13 @@ class DecodeSession:
         self._res_np = self.result.numpy() if self.poll_result else None
         self.block = torch.empty(1, self.max_bs, dtype=torch.long, device=dev)
         self._dyn_bs = None   # block size for which the draft cache's length record is already armed (see _draft)
+        # run-ahead draft (DFL_RUN_AHEAD=0 turns it off): the NEXT cycle's draft forward is enqueued right behind the
+        # accept kernel, before the host has read the acceptance length — every length it needs is in the device record
+        # the accept kernel has just written — so the GPU does not idle through the host's turnaround (result poll,
+        # bookkeeping, ~30 launches: 0.04-0.08 ms per cycle).  _ahead = block size of a draft already in flight.
+        self.run_ahead = os.environ.get("DFL_RUN_AHEAD", "1") != "0"
+        self._ahead = None
+        self._ahead_ev = None
         self._armed = False   # True: the accept kernel has written the next cycle's block (bonus token + mask ids)
         self.start = self.n_in
         self.target_hidden = None
@@ -151,9 +158,42 @@ class DecodeSession:
             e.record()
             self.events.setdefault(key, [None, None])[which] = e
 
+    def _draft_ahead(self, bs) -> None:
+        """The draft forward of the cycle AFTER the one whose accept kernel has just been enqueued (model/dflash.py:237-247
+        of the next loop iteration): lengths from the device record, context rows = the verify's tap buffer (valid count
+        = the record's tau), block = what the accept kernel re-armed.  Upper bounds for the host-side checks only."""
+        m = self.model
+        ev = None
+        if self.events is not None:   # the caller times the phases: this draft's event pairs belong to the NEXT cycle
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record()
+        hid = m.draft_block(self.dcache, th_rows=self.taps_buf[:16], tau=16, bs=bs, pos0=self.start + self.max_bs,
+                            block_ids=self.block[0], embed=self.embed_w, dyn_ready=True, s_bound=self.start + self.max_bs)
+        if ev:
+            ev[2].record()
+        _draft_ids(m, hid, self.lm_wp, bs, self.block[:, :bs], 0.0, self.draft_logits)
+        if ev:
+            ev[3].record()
+            ev[1].record()
+        self._ahead, self._ahead_ev = bs, ev
+
     def _draft(self, blk, bs, draft_steps):
         m = self.model
         ctx = self.target_hidden[0]
+        if draft_steps == 1 and self._ahead == bs:   # enqueued behind the previous cycle's accept kernel already
+            self._ahead = None
+            self.dcache.length = self.start           # rows kept (S) + this cycle's context rows (tau) = the new start
+            self._dyn_bs = None
+            if self.events is not None and self._ahead_ev:
+                e = self._ahead_ev
+                self.events["draft"], self.events["lm_head"] = [e[0], e[1]], [e[2], e[3]]
+            if self.hook is not None:
+                self.hook(blk, self.start, self.hook_calls)
+            self.hook_calls += 1
+            return
+        # (a run-ahead draft of another block size is simply abandoned: it touched scratch buffers, the draft tokens of
+        # the block and the draft cache rows this forward writes again — the length record is the accept kernel's)
+        self._ahead = None
         if draft_steps == 1:
             S = self.dcache.get_seq_length()
             head_rows = max(0, ctx.shape[0] - 16)
@@ -193,16 +233,20 @@ class DecodeSession:
 
     @torch.inference_mode()
     def cycle(self, bs: int, *, draft_steps: int = 1, want_hidden: Optional[bool] = None,
-              after_draft: Optional[Callable] = None) -> SimpleNamespace:
-        """One pass of model/dflash.py:235-268 with block size `bs` (>= 1)."""
+              after_draft: Optional[Callable] = None, ahead_ok: bool = False) -> SimpleNamespace:
+        """One pass of model/dflash.py:235-268 with block size `bs` (>= 1).  ahead_ok: the caller promises that the next
+        cycle uses the same block size whenever the tail allows it (fixed-size loops): its draft may be enqueued early."""
         start = self.start
         blk = self.block[:, :bs]
         if not self._armed:   # model/dflash.py:235; afterwards dfl_accept_commit_rearm leaves the same ids in self.block
             blk.copy_(self.output_ids[:, start:start + bs])
         if bs > 1:
-            self._mark("draft", 0)
+            ahead = draft_steps == 1 and self._ahead == bs
+            if not ahead:
+                self._mark("draft", 0)
             self._draft(blk, bs, draft_steps)
-            self._mark("draft", 1)
+            if not ahead:
+                self._mark("draft", 1)
             if after_draft is not None:
                 after_draft(blk)
         if want_hidden is None:
@@ -236,6 +280,13 @@ class DecodeSession:
         # the record now holds the next draft forward's S / tau / pos0 / start — if that cycle was a cached draft cycle
         # on this record (bs > 1, one draft step) and keeps the block size
         self._dyn_bs = bs if (bs > 1 and draft_steps == 1 and self.use_draft) else None
+        # run-ahead: the next cycle's draft goes out now if it is certain to be a draft cycle of the same block size —
+        # no tail clamp even if every token of this block is accepted, no stop tokens to end the request early, a
+        # caller-driven block size (a scheduler picks the next size only after this cycle's result: `ahead_ok`)
+        if (ahead_ok and self.run_ahead and self._dyn_bs == bs and self.native and want_hidden and self.stop_t is None
+                and not self.stop_always and self.draft_temperature < 1e-5 and bs <= 16
+                and start + 2 * bs <= self.max_length and start + self.max_bs + 16 + bs <= self.dcache.max_rows):
+            self._draft_ahead(bs)
         if self.poll_result:   # the cycle's one device->host hand-over: pinned memory, polled on the word written last
             t0 = time.perf_counter()
             while self._res_np[3] == -1:
@@ -306,7 +357,8 @@ def run_decode(model, target, input_ids: torch.Tensor, *, mask_token_id: int, ma
         want_hidden = s.use_draft if (scheduler is not None or not clamp_tail) else bs > 1
         gen_before = s.start - s.n_in
         start_idx = s.start
-        r = s.cycle(bs, draft_steps=draft_steps, want_hidden=want_hidden, after_draft=after_draft)
+        r = s.cycle(bs, draft_steps=draft_steps, want_hidden=want_hidden, after_draft=after_draft,
+                    ahead_ok=scheduler is None and draft_steps == 1)
         taus.append(r.tau)
         used_bs.append(bs)
         lgens.append(lg[0])

@@ -98,6 +98,8 @@ class DFlashDraftModel:
         self.wide_one_pass = True
         self._wide = None
         self.lm_head_events = None  # (start, end) torch.cuda.Event pair around the next lm_head GEMM launch (bench.py)
+        self.lm_head_events_log = None  # a list: every pair actually recorded is appended (a run-ahead draft uses the
+        #                                 pair of the cycle in which it is ENQUEUED)
         self.wide_prefill = True   # False: the round-1 context prefill in 16-row groups (kept for A/B timing and tests)
 
     # ------------------------------------------------------------------ weights
@@ -326,7 +328,8 @@ class DFlashDraftModel:
 
     def draft_block(self, cache: DFlashKVCache, *, th_rows: Optional[torch.Tensor], tau: int, bs: int, pos0: int,
                     block_ids: Optional[torch.Tensor] = None, embed: Optional[torch.Tensor] = None,
-                    noise: Optional[torch.Tensor] = None, append: bool = True, dyn_ready: bool = False) -> list:
+                    noise: Optional[torch.Tensor] = None, append: bool = True, dyn_ready: bool = False,
+                    s_bound: Optional[int] = None) -> list:
         """One draft forward over the block (model/dflash.py:166-190 for ctx <= 16 rows).
         Context rows `th_rows` [tau, fc_in] and the block (token ids + embedding table,
         or a ready `noise` [bs, H]) -> the row sources of the final-normed hidden states, one per
@@ -335,14 +338,21 @@ class DFlashDraftModel:
         by tau (the block rows are dropped again, as crop(start) does at :246).
         bs <= 32: blocks of 17..32 rows run as two 16-row tiles — one pass over the weights through the
         ragged-batch GEMMs (`_draft_block_wide`, returns a WideRows), or with wide_one_pass = False one launch
-        per tile of every single-request GEMM; the attention takes both query tiles either way."""
+        per tile of every single-request GEMM; the attention takes both query tiles either way.
+        s_bound (with dyn_ready, bs <= 16): the launches take S / tau / pos0 from the device record alone — the decode
+        loop enqueues this forward BEFORE the host knows the previous cycle's acceptance length (generate.py, run-ahead
+        draft).  th_rows then holds 16 rows (the valid count is the record's tau), tau / pos0 are upper bounds,
+        s_bound bounds S (it sizes the attention's key splits) and the host-side cache length is left to the caller."""
         c, ws, w = self.config, self._workspace(), self.w
         if bs < 1 or bs > 32 or tau < 0 or tau > 16:
             raise ValueError(f"bs={bs} / tau={tau}: the kernels take 1..32 block rows and 0..16 context rows")
         head = self.attn_impl == "head"
         if bs > 16 and not head:
             raise ValueError("blocks of more than 16 rows need attn_impl='head'")
-        S = cache.length
+        ahead = s_bound is not None
+        if ahead and not (dyn_ready and bs <= 16 and head and tau > 0 and noise is None):
+            raise ValueError("s_bound needs dyn_ready, a block of <= 16 rows, context rows and the 'head' attention stage")
+        S = int(s_bound) if ahead else cache.length
         if S + tau + bs > cache.max_rows:
             raise ValueError("draft KV cache too small")
         H, I = c.hidden_size, c.intermediate_size
@@ -384,7 +394,7 @@ class DFlashDraftModel:
                           n_kv=c.num_key_value_heads, q_norm_w=lw["q_norm"], k_norm_w=lw["k_norm"],
                           eps=c.rms_norm_eps, cos_tab=cos, sin_tab=sin, kcache=cache.k[i], vcache=cache.v[i],
                           scale=c.head_dim ** -0.5, causal=False, S=S, tau=tau, bs=bs, pos0=pos0,
-                          ws=ws["head_ws"], max_splits=self.max_splits)
+                          ws=ws["head_ws"], max_splits=self.max_splits, dyn=dyn if ahead else None)
                 if fuse_o:
                     ops.attn_head_oproj(**kw, attn_frag=ws["attn_frag"][0], wo=lw["o"], H=H, h_io=hrow[0],
                                         ss_out=ws["ss_h"][0], sync=ws["sync"])
@@ -409,7 +419,7 @@ class DFlashDraftModel:
             for t, dt in tiles:
                 ops.gemm_resid(lw["down"], src["act"][t], H, I, hrow[t], add_residual=True, ss_out=ws["ss_h"][t],
                                dyn=dt)
-        if append:
+        if append and not ahead:
             cache.length = S + tau
         return src["final"][:len(tiles)]
 
@@ -485,6 +495,8 @@ class DFlashDraftModel:
             if nrows <= 0:
                 continue
             ev = self.lm_head_events if t == 0 else None   # bench.py: the lm_head kernel itself between two events
+            if ev is not None and self.lm_head_events_log is not None:
+                self.lm_head_events_log.append(ev)
             ops.gemm_argmax(lm_head_wp, x, c.vocab_size, c.hidden_size, row0, nrows, ws["argmax_ws"], block_ids,
                             16 * t + row0, logits=None if logits is None else logits[16 * t:16 * t + 16],
                             margins=margins, events=ev)
