@@ -16,6 +16,8 @@ of different lengths without padding masks, which is exactly the cost this path 
 """
 from __future__ import annotations
 
+import os
+
 from types import SimpleNamespace
 from typing import Callable, Optional, Sequence
 
@@ -128,6 +130,8 @@ class BatchedDecoder:
         self.hook_calls = [0] * R
         self.bs = [16] * R
         self.events = None  # set to a dict to have cycle() record (start, end) event pairs per phase
+        self._ahead, self._ahead_ev = False, None   # a run-ahead draft is in flight (cycle(ahead_ok=True))
+        self.run_ahead = os.environ.get("DFL_RUN_AHEAD", "1") != "0"
 
     def _mark(self, key, which):
         if self.events is not None:
@@ -378,12 +382,23 @@ class BatchedDecoder:
         return self.accept(launch=False)
 
     @torch.inference_mode()
-    def cycle(self, draft_token_hook: Optional[Callable] = None, after_draft: Optional[Callable] = None) -> list:
+    def cycle(self, draft_token_hook: Optional[Callable] = None, after_draft: Optional[Callable] = None,
+              ahead_ok: bool = False) -> list:
         """One decode cycle of every live request.  draft_token_hook(r, block_row, start,
-        call): test/bench instrumentation for scripted acceptance, as in DecodeSession."""
-        self._mark("draft", 0)
-        self.draft()
-        self._mark("draft", 1)
+        call): test/bench instrumentation for scripted acceptance, as in DecodeSession.
+        ahead_ok: the caller promises that the NEXT cycle runs with the same block sizes and the same live requests
+        (no tail clamp, no request ending on this cycle's result): its draft forward — every length it needs is in the
+        device records the accept kernel writes — is then enqueued behind this cycle's accept kernel, before the host
+        reads the result, and the GPU does not idle through the host's turnaround."""
+        if self._ahead:
+            self._ahead = False
+            if self.events is not None and self._ahead_ev:
+                e = self._ahead_ev
+                self.events["draft"], self.events["lm_head"] = [e[0], e[1]], [e[2], e[3]]
+        else:
+            self._mark("draft", 0)
+            self.draft()
+            self._mark("draft", 1)
         if after_draft is not None:
             after_draft()
         if draft_token_hook is not None:
@@ -394,7 +409,22 @@ class BatchedDecoder:
         self._mark("target", 0)
         self.verify()
         self._mark("target", 1)
-        return self.accept()
+        if not (ahead_ok and self.run_ahead):
+            return self.accept()
+        self._accept_launch()
+        ev = None
+        if self.events is not None:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record()
+        self._draft_body(self._kv_len_max() + 16)   # (the new starts are at most 16 rows further)
+        if ev:
+            ev[2].record()
+        self._draft_head()
+        if ev:
+            ev[3].record()
+            ev[1].record()
+        self._ahead, self._ahead_ev = True, ev
+        return self.accept(launch=False)
 
 
 @torch.inference_mode()
@@ -435,12 +465,15 @@ def dflash_generate_batch(model: DFlashDraftModel, target: NativeTarget, input_i
             for r in range(len(idx)):  # tail clamp (benchmark.py:104-105)
                 if dec.live[r]:
                     dec.set_block_size(r, max(1, min(block_size, max_len[r] - dec.start[r])))
+            # run-ahead draft: only while no live request can finish or hit its tail clamp on this cycle's result
+            ahead = (stop_token_ids is None and not stop_always
+                     and all(dec.start[r] + 2 * block_size <= max_len[r] for r in range(len(idx)) if dec.live[r]))
             if first:   # the clock restarts after the first draft, before its verify (benchmark.py:145-147)
                 first = False
-                out = dec.cycle(hook, after_draft=lambda: clock.__setitem__(0, cuda_time()))
+                out = dec.cycle(hook, after_draft=lambda: clock.__setitem__(0, cuda_time()), ahead_ok=ahead)
                 t1 = clock[0]
             else:
-                out = dec.cycle(hook)
+                out = dec.cycle(hook, ahead_ok=ahead)
             for r, o in enumerate(out):
                 if o is None:
                     continue
