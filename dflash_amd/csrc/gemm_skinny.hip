@@ -534,6 +534,109 @@ __global__ __launch_bounds__(1024) void k_gemm(GemmArgs a) {
   gemm_body<MT, CHUNKED, EPI, NORM>(a);
 }
 
+// ---- K-chunked residual GEMM, second form (round 3): 8 waves x 8 k-steps per item and THREE rotating buffers.
+// The 16-wave form above holds two 64 KB items per workgroup at 128 VGPRs (one in flight while one is in the MFMAs);
+// a 512-thread workgroup alone on a CU gives each wave 256 VGPRs: three weight buffers + three activation buffers
+// (192 VGPRs), i.e. TWO items = 128 KB per CU in flight while the third is in the MFMAs.  Every request is
+// unconditional (a zero-length descriptor past the last item) and pinned in front of the MFMAs, as in gemm_batch.hip:
+// with 8 waves per CU a wave's own pipelining matters.  Plain / fragment row sources only (mode 0 / 1); one LDS
+// meeting per TILE (the K chunks of a tile accumulate in registers).  down_proj and the draft's fc.
+template <int DUMMY>
+__global__ __launch_bounds__(512) void k_gemm_chunk8(GemmArgs a) {
+  constexpr int FR = 8, NW = 8;
+  __shared__ float red[2][NW][256];
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = tid & 63;
+  const RowSrc &src = a.src[0];
+  const int nv = (src.valid_word >= 0 && a.dyn) ? a.dyn[src.valid_word] : 16;  // asked for before any vector load
+  __builtin_amdgcn_sched_barrier(0);
+  const int stride = gridDim.x;
+  const int nseq = (int)blockIdx.x < a.ntiles ? (a.ntiles - 1 - (int)blockIdx.x) / stride + 1 : 0;
+  const int nitems = nseq * a.nch;
+  auto ks0_of = [&](int c) { return (c * NW + w) * FR; };
+  auto nf_of = [&](int c) {
+    const int nf = a.KS - ks0_of(c);
+    return nf < 0 ? 0 : (nf > FR ? FR : nf);
+  };
+  bf16x8 wA[FR], wB[FR], wC[FR], xA[FR], xB[FR], xC[FR];
+  // item i = (tile blockIdx.x + (i / nch) * stride, chunk i % nch); live = false: a dummy (no weight traffic; the
+  // activation fragments of the last real chunk once more, from L2)
+  auto load_item = [&](bf16x8(&wr)[FR], bf16x8(&xr)[FR], int i, bool live) {
+    const int ii = live ? i : (nitems > 0 ? nitems - 1 : 0);
+    const int t = (int)blockIdx.x + (ii / a.nch) * stride, c = ii % a.nch;
+    load_ksteps<FR>(wr, a.wp + ((size_t)t * a.KS + ks0_of(c)) * 64, live ? nf_of(c) : 0, l);
+    int ks[FR];
+#pragma unroll
+    for (int f = 0; f < FR; ++f) ks[f] = ks0_of(c) + f < a.KS ? ks0_of(c) + f : a.KS - 1;
+    bf16x8 wv[FR];
+#pragma unroll
+    for (int f = 0; f < FR; ++f) wv[f] = xr[f] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    issue_x<FR, false>(src, ks, l, nv, xr, wv);
+  };
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  bf16_t resid0 = (bf16_t)0.f;
+  auto process = [&](bf16x8(&wr)[FR], bf16x8(&xr)[FR], int i) {
+    const int pos = i / a.nch, c = i - pos * a.nch, t = (int)blockIdx.x + pos * stride;
+    if (c == 0) acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int ks0c = ks0_of(c);
+#pragma unroll
+    for (int f = 0; f < FR; ++f) {
+      const bool keep = ks0c + f < a.KS && (src.mode == 0 || (l & 15) < nv);
+      const bf16x8 xv = keep ? xr[f] : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[f], xv, acc, 0, 0, 0);
+    }
+    if (c != a.nch - 1) return;
+    const int buf = pos & 1;
+    *reinterpret_cast<f32x4 *>(&red[buf][w][l * 4]) = acc;
+    __syncthreads();
+    if (tid < 256) {  // row m = tid >> 4, column nl = tid & 15 of the tile (D layout as in gemm_body)
+      const int m = tid >> 4, nl = tid & 15;
+      const int idx = 4 * (m + 16 * (nl >> 2)) + (nl & 3);
+      float sum = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < NW; ++ww) sum += red[buf][ww][idx];
+      const int n = t * 16 + nl;
+      const float v = rbf(sum);
+      bf16_t *hp = a.h_io + (int64_t)m * a.ldh + n;
+      float hn = v;
+      if (a.add_resid) hn = rbf(bf2f(pos == 0 ? resid0 : *hp) + v);
+      *hp = f2bf(hn);
+      if (a.tap) a.tap[(int64_t)m * a.ldtap + n] = f2bf(hn);
+      const float q = row_sum16(hn * hn);
+      if (nl == 0 && a.ss_out) a.ss_out[t * 16 + m] = q;
+    }
+  };
+  // prologue: two items leave, then the first tile's residual value (every thread asks: no branch around a load)
+  load_item(wA, xA, 0, nitems > 0);
+  load_item(wB, xB, 1, nitems > 1);
+  {
+    const int ff = tid & 255;
+    resid0 = a.h_io[(int64_t)(ff >> 4) * a.ldh + (int)blockIdx.x * 16 + (ff & 15)];
+  }
+  for (int j = 0; j < nitems; j += 3) {
+    load_item(wC, xC, j + 2, j + 2 < nitems);
+    __builtin_amdgcn_sched_barrier(0);
+    process(wA, xA, j);
+    if (j + 1 >= nitems) break;
+    __builtin_amdgcn_sched_barrier(0);
+    load_item(wA, xA, j + 3, j + 3 < nitems);
+    __builtin_amdgcn_sched_barrier(0);
+    process(wB, xB, j + 1);
+    if (j + 2 >= nitems) break;
+    __builtin_amdgcn_sched_barrier(0);
+    load_item(wB, xB, j + 4, j + 4 < nitems);
+    __builtin_amdgcn_sched_barrier(0);
+    process(wC, xC, j + 2);
+  }
+}
+
+// Measured (scripts/ab_prof.sh, same box, in the cycle): down_proj 22.98 us against 20.50 us for the 16-wave form —
+// twice the bytes in flight per CU, half the waves: slower, like every other deeper queue tried in rounds 2 and 3.
+#ifndef DFL_CHUNK8  // A/B switch: 1 = the K-chunked residual GEMM runs as k_gemm_chunk8 (8 waves, three buffers)
+#define DFL_CHUNK8 0
+#endif
+
 // the instantiation for this launch's row sources (a normalised source needs the NORM kernels)
 template <int MT, bool CHUNKED, int EPI>
 void launch_gemm(const GemmArgs &a, dim3 grid, hipStream_t stream) {
@@ -851,8 +954,11 @@ extern "C" int dfl_gemm_resid(const void *wp, const dfl_rows *x, int N, int K, v
   } else {  // walk K in chunks of 16 waves x 4 steps inside the workgroup
     DFL_REQUIRE(a.src[0].mode != 2, "dfl_gemm_resid: a normalised source needs K <= 4096");
     a.nfr = 4;
-    a.nch = (KS + 63) / 64;
-    launch_gemm<1, true, EPI_RESID>(a, grid, (hipStream_t)stream);
+    a.nch = (KS + 63) / 64;  // 64 k-steps per chunk in both forms: 16 waves x 4, or 8 waves x 8
+    if (DFL_CHUNK8)
+      hipLaunchKernelGGL((k_gemm_chunk8<0>), grid, dim3(512), 0, (hipStream_t)stream, a);
+    else
+      launch_gemm<1, true, EPI_RESID>(a, grid, (hipStream_t)stream);
   }
   DFL_CHECK_LAUNCH("dfl_gemm_resid");
   return DFL_OK;
