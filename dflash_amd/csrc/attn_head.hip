@@ -921,7 +921,11 @@ int attn_head_launch(const void *xq, int64_t ldq, int q_col, int k_col, int v_co
   // per workgroup halve the K/V pulled through L2 and double the splits.  DFL_ATTN_HEAD_PAIR=0/1 forces it off / on.
   static const int knob_pair = [] { const char *e = getenv("DFL_ATTN_HEAD_PAIR"); return e ? atoi(e) : -1; }();
   // Measured on the 8B shapes (cycle, ms): S = 2048 4.28 -> 4.40 (worse), 4096 4.48 -> 4.49, 8192 4.78 -> 4.68: on from ~5k keys.
-  bool pair = !tail && q_tiles == 1 && G % 2 == 0 && bs <= 16 && nt > tiles * ns_old && nt > 160;
+  // Several blocks per launch (requests of a ragged batch, candidates): the one round of workgroups leaves a single
+  // old-key split per head from two requests on, i.e. ~4 tiles per wave at S = 1k — pairs on whenever the budget
+  // leaves a wave more than one tile (round 3, same box: 4 requests 6.03 -> 5.81 ms per cycle, 3 requests 5.97 -> 5.69;
+  // 2 requests 5.22 -> 5.29: from three blocks on).
+  bool pair = !tail && q_tiles == 1 && G % 2 == 0 && bs <= 16 && nt > tiles * ns_old && (nt > 160 || n_cand > 2);
   if (knob_pair >= 0) pair = pair_ok_forced(knob_pair, tail != nullptr, q_tiles, G, bs);
   if (pair) {
     int budget2 = (n_cand > 1 ? knob_wgsm : knob_wgs) / ((n_q / 2) * n_cand) - 1;
