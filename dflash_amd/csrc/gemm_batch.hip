@@ -402,6 +402,11 @@ __global__ __launch_bounds__(256) void k_embed_rows_b(const bf16_t *embed, const
 // Batched GEMMs take normalised rows from here rather than normalising in their prologue: that
 // prologue runs in every workgroup (128x redundant) and at 4 request tiles costs ~10 us of VALU
 // per launch (qkv 25.6 us with the normed source vs 15.2 us from frag16).
+// Round 3: every load of the row (residual chunks, the K-part sums of all parts) is requested up front, before the
+// row-validity word — a dependent scalar load — is looked at; the new row stays in registers across the barrier
+// instead of being re-read (6.5 -> see DESIGN.md section 6b us per launch, 82 launches per 4-request cycle).
+// MAXC chunks of 8 columns per thread: H <= 2048 * MAXC.
+template <int MAXC>
 __global__ __launch_bounds__(256) void k_norm_frag_b(bf16_t *h, int64_t h_stride, int64_t ldh, const float *part,
                                                      int nsplit, int64_t part_split, int ldp, bf16_t *tap,
                                                      int64_t ldtap, int64_t tap_stride, const bf16_t *nw, float eps,
@@ -409,51 +414,69 @@ __global__ __launch_bounds__(256) void k_norm_frag_b(bf16_t *h, int64_t h_stride
                                                      int dyn_word) {
   __shared__ float wsum[4];
   const int m = blockIdx.x, r = blockIdx.y, tid = threadIdx.x;
-  const int nv = dyn ? dyn[r * DFL_DYN_WORDS + dyn_word] : 16;
+  const int nv = dyn ? dyn[r * DFL_DYN_WORDS + dyn_word] : 16;  // (used only after the loads below have been requested)
   const int nchunks = H >> 3;
   bf16x8 *out = frag + r * frag_stride8;
-  if (m >= nv) {
+  bf16_t *row = h + r * h_stride + (int64_t)m * ldh;
+  const float *prow = part ? part + (int64_t)(r * 16 + m) * ldp : nullptr;
+  bf16x8 v[MAXC], wv[MAXC];
+  float acc[MAXC][8];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = tid + i * 256, cc = c < nchunks ? c : nchunks - 1;  // clamped: no branch around a load
+    v[i] = *reinterpret_cast<const bf16x8 *>(row + cc * 8);
+    wv[i] = *reinterpret_cast<const bf16x8 *>(nw + cc * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+  }
+  if (prow) {  // uniform
+    for (int k = 0; k < nsplit; ++k) {  // fixed part order
+#pragma unroll
+      for (int i = 0; i < MAXC; ++i) {
+        const int c = tid + i * 256, cc = c < nchunks ? c : nchunks - 1;
+        const f32x4 p0 = *reinterpret_cast<const f32x4 *>(prow + k * part_split + cc * 8);
+        const f32x4 p1 = *reinterpret_cast<const f32x4 *>(prow + k * part_split + cc * 8 + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[i][j] += p0[j];
+          acc[i][4 + j] += p1[j];
+        }
+      }
+    }
+  }
+  if (m >= nv) {  // uniform per workgroup
     const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int c = tid; c < nchunks; c += 256) out[c * 16 + m] = z;
     return;
   }
-  bf16_t *row = h + r * h_stride + (int64_t)m * ldh;
-  const float *prow = part ? part + (int64_t)(r * 16 + m) * ldp : nullptr;
   float ss = 0.f;
-  for (int c = tid; c < nchunks; c += 256) {
-    bf16x8 v = *reinterpret_cast<const bf16x8 *>(row + c * 8);
-    if (prow) {
-      float acc[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-      for (int k = 0; k < nsplit; ++k) {  // fixed part order
-        const f32x4 p0 = *reinterpret_cast<const f32x4 *>(prow + k * part_split + c * 8);
-        const f32x4 p1 = *reinterpret_cast<const f32x4 *>(prow + k * part_split + c * 8 + 4);
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = tid + i * 256;
+    if (c < nchunks) {
+      if (prow) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          acc[j] += p0[j];
-          acc[4 + j] += p1[j];
-        }
+        for (int j = 0; j < 8; ++j) v[i][j] = f2bf(bf2f(v[i][j]) + rbf(acc[i][j]));  // Linear output in bf16, then the add
+        *reinterpret_cast<bf16x8 *>(row + c * 8) = v[i];
       }
+      if (tap) *reinterpret_cast<bf16x8 *>(tap + r * tap_stride + (int64_t)m * ldtap + c * 8) = v[i];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(v[j]) + rbf(acc[j]));  // Linear output in bf16, then the add
-      *reinterpret_cast<bf16x8 *>(row + c * 8) = v;  // re-read below by this same thread
+      for (int j = 0; j < 8; ++j) ss += bf2f(v[i][j]) * bf2f(v[i][j]);
     }
-    if (tap) *reinterpret_cast<bf16x8 *>(tap + r * tap_stride + (int64_t)m * ldtap + c * 8) = v;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ss += bf2f(v[j]) * bf2f(v[j]);
   }
   ss = wave_sum(ss);
   if ((tid & 63) == 0) wsum[tid >> 6] = ss;
   __syncthreads();
   const float rstd = rsqrtf((wsum[0] + wsum[1] + wsum[2] + wsum[3]) / (float)H + eps);
-  for (int c = tid; c < nchunks; c += 256) {
-    const bf16x8 v = *reinterpret_cast<const bf16x8 *>(row + c * 8);  // own store / L1 hit
-    const bf16x8 wv = *reinterpret_cast<const bf16x8 *>(nw + c * 8);
-    bf16x8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(wv[j]) * rbf(bf2f(v[j]) * rstd));
-    out[c * 16 + m] = o;
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = tid + i * 256;
+    if (c < nchunks) {
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(wv[i][j]) * rbf(bf2f(v[i][j]) * rstd));
+      out[c * 16 + m] = o;
+    }
   }
 }
 
@@ -621,9 +644,18 @@ extern "C" int dfl_norm_frag_batch(void *h, int64_t h_stride, int64_t ldh, int R
   DFL_REQUIRE(R >= 1 && R <= 4, "dfl_norm_frag_batch: R outside 1..4");
   DFL_REQUIRE(!part || (nsplit >= 1 && ldp >= H && ldp % 4 == 0), "dfl_norm_frag_batch: bad partial layout");
   DFL_REQUIRE(!tap || (ldtap >= H && ldtap % 8 == 0), "dfl_norm_frag_batch: bad tap layout");
-  hipLaunchKernelGGL(k_norm_frag_b, dim3(16, R), dim3(256), 0, (hipStream_t)stream, (bf16_t *)h, h_stride, ldh, part, nsplit,
-                     part_split, ldp, (bf16_t *)tap, ldtap, tap_stride, (const bf16_t *)norm_w, eps, (bf16x8 *)frag,
-                     frag_stride / 8, H, dyn, dyn_word);
+  DFL_REQUIRE(H <= 2048 * 8, "dfl_norm_frag_batch: H = %d exceeds 16384", H);
+#define DFL_NORM_B(MAXC)                                                                                                  \
+  hipLaunchKernelGGL((k_norm_frag_b<MAXC>), dim3(16, R), dim3(256), 0, (hipStream_t)stream, (bf16_t *)h, h_stride, ldh,   \
+                     part, nsplit, part_split, ldp, (bf16_t *)tap, ldtap, tap_stride, (const bf16_t *)norm_w, eps,       \
+                     (bf16x8 *)frag, frag_stride / 8, H, dyn, dyn_word)
+  if (H <= 2048 * 2)
+    DFL_NORM_B(2);
+  else if (H <= 2048 * 4)
+    DFL_NORM_B(4);
+  else
+    DFL_NORM_B(8);
+#undef DFL_NORM_B
   DFL_CHECK_LAUNCH("dfl_norm_frag_batch");
   return DFL_OK;
 }
