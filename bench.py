@@ -172,7 +172,7 @@ def gpu_leg(args, rank, world, dev):
         ttft_side = {"target_prefill_ms": 1e3 * (t_c0 - t_pf), "cycle0_ms": 1e3 * (time.perf_counter() - t_c0),
                      "note": "second request on warm code (outside the timed region): the target prefill runs "
                              + ("through the wrapped HF model" if (args.hf_verify or args.hf_prefill) else
-                                "on the kernels (csrc/prefill.hip: MFMA GEMMs on the packed weights; attention core torch SDPA)")
+                                "on the kernels (csrc/prefill.hip: MFMA GEMMs on the packed weights, causal attention, norm / RoPE / cache write)")
                              + f"; cycle 0 = projection of the {P} prompt context rows into the draft cache "
                              "(model/dflash.py:73-85, 64 rows per pass) + one decode cycle"}
     s.cycle(bs, ahead_ok=True)       # first steady-state cycle: one-off code-object loads (60 ms) — setup, like cycle 0

@@ -80,6 +80,7 @@ SIGNATURES = {
     "dfl_prefill_gemm_silu": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "dfl_prefill_norm_pack": (_i, [_p, _i64, _i, _i, _p, _f, _p, _p]),
     "dfl_prefill_qk_rope": (_i, [_p, _i64, _i, _i, _i, _i, _i, _i, _p, _p, _f, _p, _p, _i, _i, _p, _p, _i, _i, _p]),
+    "dfl_prefill_attn": (_i, [_p, _i64, _i, _p, _p, _i, _i, _i, _i, _f, _p, _p]),
     # ---- ragged batch of requests
     "dfl_batch_tiles": (_i, [_i]),
     "dfl_batch_ksplit": (_i, [_i]),

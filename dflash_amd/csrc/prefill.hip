@@ -242,6 +242,171 @@ __global__ __launch_bounds__(256) void k_pqk_rope(PRopeArgs a) {
   }
 }
 
+// Causal attention of the prompt over itself (tf:modeling_qwen3.py eager / SDPA attention of the target's prefill
+// forward, model/dflash.py:218-225): softmax(q k^T * scale, causal) v per query head, GQA.  One WAVE per (query head,
+// 16-row query tile), no barrier anywhere: the wave walks its 32-key tiles up to the diagonal with the next tile in
+// flight — K fragments L2 -> VGPR directly in MFMA A-operand order, V rows through a wave-private 8 KB LDS tile for
+// ds_read_b64_tr_b16 — S^T = K Q^T and O^T += V^T P^T on v_mfma_f32_16x16x32_bf16 with the base-2 online softmax of
+// csrc/attn_head.hip (same fragment layouts; P rounded to bf16 for the PV product).  The four waves of a workgroup take
+// four consecutive query tiles of one head (the same K/V rows, from L1 / L2); heavy tiles (late rows) are dealt first.
+// q: post-norm, post-RoPE bf16 rows (dfl_prefill_qk_rope rewrote them in place); K/V: the cache rows it wrote.
+// Output: frag16 row tiles of n_q * 128 columns — o_proj's operand, no pack step in between.
+struct PAttnArgs {
+  const bf16_t *q;
+  int64_t ldq;
+  int q_col;
+  const bf16_t *kc, *vc;
+  int cache_rows, P, G;
+  float scale_log2;
+  bf16x8 *out_frag;
+  int KSo;  // n_q * 128 / 32
+};
+
+typedef __attribute__((address_space(3))) bf16x4 plds_bf16x4;
+__device__ __forceinline__ int pv_swz(int row, int ch) { return row * 256 + ((((ch >> 1) ^ (row & 7)) << 5) | ((ch & 1) << 4)); }
+__device__ __forceinline__ void pswap16(float &a, float &b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void pswap32(float &a, float &b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ float pg_max(float v) {  // max over the four 16-lane rows of the wave (csrc/attn_head.hip)
+  float a = v, b = v;
+  pswap16(a, b);
+  a = b = fmaxf(a, b);
+  pswap32(a, b);
+  return fmaxf(a, b);
+}
+__device__ __forceinline__ float pg_sum(float v) {
+  float a = v, b = v;
+  pswap16(a, b);
+  a = b = a + b;
+  pswap32(a, b);
+  return a + b;
+}
+
+__global__ __launch_bounds__(256) void k_pattn(PAttnArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds[4 * 8192];
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = tid & 63, qi = l & 15, g = l >> 4;
+  const int head = blockIdx.y;
+  const int nqt = (a.P + 15) >> 4;
+  const int t = nqt - 1 - ((int)blockIdx.x * 4 + w);  // wave-uniform; late (long) tiles first
+  if (t < 0) return;                                  // the whole wave leaves: no barrier in this kernel
+  const bf16_t *K = a.kc + (int64_t)(head / a.G) * a.cache_rows * 128;
+  const bf16_t *V = a.vc + (int64_t)(head / a.G) * a.cache_rows * 128;
+  char *my_v = lds + w * 8192;
+  const int qrow = t * 16 + qi, qrow_c = qrow < a.P ? qrow : a.P - 1;
+  bf16x8 qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+    qf[s] = *reinterpret_cast<const bf16x8 *>(a.q + (int64_t)qrow_c * a.ldq + a.q_col + head * 128 + 32 * s + 8 * g);
+  const int kend = (t * 16 + 16 < a.P ? t * 16 + 16 : a.P);  // keys [0, kend) are visible to some row of this tile
+  const int ntile = (kend + 31) >> 5;
+  // tile fetch: K fragments (lane: key u*16 + qi, d = 32 s + 8 g ..) and the V rows (chunk c = l + 64 i of the 32 x 16
+  // 16-byte chunks); rows past the last prompt row are clamped (their scores are masked, their V rows never read)
+  auto fetch = [&](bf16x8(&kf)[2][4], bf16x8(&vr)[8], int tile) {
+    const int key0 = tile * 32;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      int kr = key0 + u * 16 + qi;
+      kr = kr < a.P ? kr : a.P - 1;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) kf[u][s] = *reinterpret_cast<const bf16x8 *>(K + (int64_t)kr * 128 + 32 * s + 8 * g);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = l + 64 * i;
+      int vrw = key0 + (c >> 4);
+      vrw = vrw < a.P ? vrw : a.P - 1;
+      vr[i] = *reinterpret_cast<const bf16x8 *>(V + (int64_t)vrw * 128 + (c & 15) * 8);
+    }
+  };
+  auto put_v = [&](const bf16x8(&vr)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = l + 64 * i;
+      *reinterpret_cast<bf16x8 *>(my_v + pv_swz(c >> 4, c & 15)) = vr[i];
+    }
+  };
+  f32x4 o[8];
+#pragma unroll
+  for (int dt = 0; dt < 8; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+  auto compute = [&](const bf16x8(&kf)[2][4], int key0) {
+    const int qq = qi >> 2, p4 = l & 3;
+    int vrows = a.P - key0;
+    vrows = vrows > 32 ? 32 : vrows;
+    int r0 = 4 * g + qq, r1 = 16 + 4 * g + qq;
+    r0 = r0 < vrows ? r0 : vrows - 1;  // (rows past the data hold stale LDS bytes: P is 0 there, but 0 x NaN is not)
+    r1 = r1 < vrows ? r1 : vrows - 1;
+    f32x4 sc[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      sc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) sc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[u][s], qf[s], sc[u], 0, 0, 0);
+    }
+    float mx = -INFINITY;  // lane (q = qi, g): sc[u][r] is key key0 + u * 16 + 4 g + r
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = key0 + u * 16 + 4 * g + r;
+        const float v = (key <= qrow && key < a.P) ? sc[u][r] * a.scale_log2 : -INFINITY;
+        sc[u][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = pg_max(mx);
+    const float m_new = fmaxf(m_run, mx);
+    const float m_ref = m_new == -INFINITY ? 0.f : m_new;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_ref);
+    m_run = m_new;
+    float psum = 0.f;
+    bf16x8 pb;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __builtin_amdgcn_exp2f(sc[u][r] - m_ref);
+        psum += p;
+        pb[u * 4 + r] = f2bf(p);
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) o[dt] *= alpha;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) {
+      const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((plds_bf16x4 *)(my_v + r0 * 256 + (((dt ^ (r0 & 7)) << 5) | (p4 << 3))));
+      const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((plds_bf16x4 *)(my_v + r1 * 256 + (((dt ^ (r1 & 7)) << 5) | (p4 << 3))));
+      const bf16x8 va = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb, o[dt], 0, 0, 0);
+    }
+  };
+  // the walk: every fetch unconditional (past the last tile: the last tile once more), so that hipcc can count the loads
+  // in flight instead of waiting vmcnt(0) behind a conditional request (csrc/attn_head.hip)
+  bf16x8 kA[2][4], kB[2][4], vA[8], vB[8];
+  fetch(kA, vA, 0);
+  for (int tc = 0; tc < ntile; tc += 2) {
+    fetch(kB, vB, tc + 1 < ntile ? tc + 1 : ntile - 1);
+    put_v(vA);
+    compute(kA, tc * 32);
+    fetch(kA, vA, tc + 2 < ntile ? tc + 2 : ntile - 1);
+    if (tc + 1 < ntile) {
+      put_v(vB);
+      compute(kB, (tc + 1) * 32);
+    }
+  }
+  // O^T tile dt: lane (q = qi, g) holds d = dt * 16 + 4 g + r  ->  frag16: column k = head * 128 + d of row tile t
+  const float inv = 1.f / pg_sum(l_run);
+  bf16x8 *base = a.out_frag + (size_t)t * a.KSo * 64;
+#pragma unroll
+  for (int dt = 0; dt < 8; ++dt) {
+    bf16x4 ov;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ov[r] = f2bf(qrow < a.P ? o[dt][r] * inv : 0.f);
+    bf16_t *dst = reinterpret_cast<bf16_t *>(base + (head * 4 + (dt >> 1)) * 64 + ((dt & 1) * 2 + (g >> 1)) * 16 + qi) + (g & 1) * 4;
+    *reinterpret_cast<bf16x4 *>(dst) = ov;
+  }
+}
+
 bool pgemm_fill(PGemmArgs &a, const void *wp, const void *xf, int P, int N, int K, const char *who) {
   if (!wp || !xf) {
     dfl_set_error("%s: null pointer", who);
@@ -335,5 +500,18 @@ extern "C" int dfl_prefill_qk_rope(void *qkv_rows, int64_t ld, int P, int q_col,
   const int64_t items = (int64_t)P * (n_q + 2 * n_kv);
   hipLaunchKernelGGL(k_pqk_rope, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
   DFL_CHECK_LAUNCH("dfl_prefill_qk_rope");
+  return DFL_OK;
+}
+
+extern "C" int dfl_prefill_attn(const void *q_rows, int64_t ldq, int q_col, const void *kcache, const void *vcache,
+                                int cache_rows, int P, int n_q, int n_kv, float scale, void *out_frag, void *stream) {
+  DFL_REQUIRE(q_rows && kcache && vcache && out_frag, "dfl_prefill_attn: null pointer");
+  DFL_REQUIRE(P >= 1 && P <= cache_rows && n_q >= 1 && n_kv >= 1 && n_q % n_kv == 0 && ldq % 8 == 0 && q_col % 8 == 0,
+              "dfl_prefill_attn: bad shape (P=%d cache_rows=%d n_q=%d n_kv=%d)", P, cache_rows, n_q, n_kv);
+  PAttnArgs a{(const bf16_t *)q_rows, ldq, q_col, (const bf16_t *)kcache, (const bf16_t *)vcache, cache_rows, P, n_q / n_kv,
+              scale * 1.4426950408889634f, (bf16x8 *)out_frag, n_q * 4};
+  const int nqt = (P + 15) / 16;
+  hipLaunchKernelGGL(k_pattn, dim3((nqt + 3) / 4, n_q), dim3(256), 0, (hipStream_t)stream, a);
+  DFL_CHECK_LAUNCH("dfl_prefill_attn");
   return DFL_OK;
 }

@@ -675,3 +675,13 @@ def prefill_qk_rope(qkv: torch.Tensor, P: int, q_col: int, k_col: int, v_col: in
                                     _p(cos_tab, BF16, "cos"), _p(sin_tab, BF16, "sin"), cos_tab.shape[0], pos0,
                                     _p(kcache, BF16, "kcache"), _p(vcache, BF16, "vcache"), kcache.shape[1], row0,
                                     _stream()), "dfl_prefill_qk_rope")
+
+
+def prefill_attn(qkv: torch.Tensor, P: int, q_col: int, kcache, vcache, n_q: int, n_kv: int, scale: float,
+                 out_frag: torch.Tensor) -> None:
+    """Causal attention of the prompt rows over themselves -> frag16 row tiles of n_q * 128 columns."""
+    assert qkv.dtype == BF16 and qkv.stride(1) == 1 and kcache.shape == vcache.shape and kcache.shape[2] == 128
+    assert out_frag.numel() >= (P + 15) // 16 * 16 * n_q * 128
+    check(lib().dfl_prefill_attn(qkv.data_ptr(), qkv.stride(0), q_col, _p(kcache, BF16, "kcache"), _p(vcache, BF16, "vcache"),
+                                 kcache.shape[1], P, n_q, n_kv, scale, _p(out_frag, BF16, "out_frag"), _stream()),
+          "dfl_prefill_attn")

@@ -221,6 +221,7 @@ class NativeTarget:
         self._pf = None
         self.native_prefill = (prefill == "native" and not self.is_moe and (q_dim + 2 * kv_dim) % 128 == 0
                                and self.H % 128 == 0 and self.I % 64 == 0 and q_dim % 64 == 0)
+        self.prefill_attn = "native"   # "sdpa": the causal attention core of the prefill through torch (round-3 first form)
         self._rotary = getattr(hf_model.model, "rotary_emb", None)
         if not keep_hf:
             if not self.native_prefill:
@@ -281,8 +282,8 @@ class NativeTarget:
 
     def _prefill_native(self, input_ids, cache, output_hidden_states, tap_layers):
         """The prompt rows on the kernels: per layer RMSNorm -> frag16 tiles, q/k/v GEMM (bf16 rows), q/k-norm + RoPE +
-        cache write, causal attention over the prompt (torch SDPA on the rows the kernels produced — the one stage of
-        the prefill still outside csrc/: 0.3 of the pass's 14 TFLOP), o_proj + residual, RMSNorm, gate/up + SiLU,
+        cache write, causal attention over the prompt (k_pattn: one wave per head and 16-row query tile), o_proj +
+        residual, RMSNorm, gate/up + SiLU,
         down_proj + residual (+ tap).  Last row: final norm + lm_head through the decode path's skinny GEMM."""
         import torch.nn.functional as F
         P = input_ids.shape[1]
@@ -311,11 +312,14 @@ class NativeTarget:
             ops.prefill_gemm_rows(lw["qkv"], xf, P, nqkv, H, qkv)
             ops.prefill_qk_rope(qkv, P, 0, q_dim, q_dim + kv_dim, self.n_q, self.n_kv, lw["q_norm"], lw["k_norm"], self.eps,
                                 cos, sin, 0, cache.k[i], cache.v[i], 0)
-            q = qkv[:P, :q_dim].view(P, self.n_q, 128).transpose(0, 1).unsqueeze(0)
-            o = F.scaled_dot_product_attention(q, cache.k[i][:, :P].unsqueeze(0), cache.v[i][:, :P].unsqueeze(0),
-                                               is_causal=True, scale=128 ** -0.5, enable_gqa=self.n_kv != self.n_q)
-            attn[:P].view(P, self.n_q, 128).copy_(o[0].transpose(0, 1))
-            ops.prefill_norm_pack(attn, P, q_dim, None, self.eps, xf)      # rows -> frag16 tiles, no norm
+            if self.prefill_attn == "native":   # csrc/prefill.hip:k_pattn, straight into o_proj's frag16 operand
+                ops.prefill_attn(qkv, P, 0, cache.k[i], cache.v[i], self.n_q, self.n_kv, 128 ** -0.5, xf)
+            else:                               # torch SDPA on the same rows (second implementation: tests, A/B)
+                q = qkv[:P, :q_dim].view(P, self.n_q, 128).transpose(0, 1).unsqueeze(0)
+                o = F.scaled_dot_product_attention(q, cache.k[i][:, :P].unsqueeze(0), cache.v[i][:, :P].unsqueeze(0),
+                                                   is_causal=True, scale=128 ** -0.5, enable_gqa=self.n_kv != self.n_q)
+                attn[:P].view(P, self.n_q, 128).copy_(o[0].transpose(0, 1))
+                ops.prefill_norm_pack(attn, P, q_dim, None, self.eps, xf)      # rows -> frag16 tiles, no norm
             ops.prefill_gemm_resid(lw["o"], xf, P, H, q_dim, h)
             ops.prefill_norm_pack(h, P, H, lw["ln2"], self.eps, xf)
             ops.prefill_gemm_silu(lw["gu"], xf, P, I, H, act)

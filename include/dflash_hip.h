@@ -380,6 +380,13 @@ int dfl_prefill_qk_rope(void *qkv_rows, int64_t ld, int P, int q_col, int k_col,
                         const void *q_norm_w, const void *k_norm_w, float eps, const void *cos_tab, const void *sin_tab,
                         int max_pos, int pos0, void *kcache, void *vcache, int cache_rows, int row0, void *stream);
 
+/* Causal attention of the P prompt rows over themselves (GQA, head_dim 128): q = the rows dfl_prefill_qk_rope left in
+ * the q/k/v row buffer (row stride ldq, q columns from q_col), K/V = cache rows [0, P) it wrote.  softmax(q k^T * scale)
+ * v in fp32 with P rounded to bf16 for the PV product (as dfl_attn_head).  out_frag: frag16 row tiles of n_q * 128
+ * columns (o_proj's operand); the tiles of rows >= P within the last written tile are zero. */
+int dfl_prefill_attn(const void *q_rows, int64_t ldq, int q_col, const void *kcache, const void *vcache, int cache_rows,
+                     int P, int n_q, int n_kv, float scale, void *out_frag, void *stream);
+
 /* ======================================================================================
  * Ragged batch of requests on one GPU (BASELINE.json configs[2]; SURVEY.md §8e: "within a
  * GPU the requests are a ragged batch for the kernels: shared weight stream, per-request

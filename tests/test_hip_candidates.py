@@ -243,3 +243,21 @@ def test_candidate_loop_on_hf_target_path():
             o = hf(nxt, past_key_values=c, use_cache=True)
     assert r.output_ids[0].tolist() == ar[0].tolist()
     assert all(x["num_candidates"] == 3 for x in r.cycle_trace if x["effective_block_size"] > 2)
+
+
+def test_topk_rows_with_masked_vocabulary_entries():
+    """-inf logits (a masked vocabulary range, also as the FIRST entries a thread sees) add nothing to the log-sum-exp —
+    torch.log_softmax handles them; exp(-inf - -inf) must not poison the row."""
+    from dflash_amd import ops
+    g = torch.Generator().manual_seed(8)
+    x = (torch.randn(5, 4096, generator=g) * 3).to(BF16)
+    x[0, :1024] = float("-inf")           # every thread's first chunk
+    x[1, ::2] = float("-inf")
+    x[2, 100:4000] = float("-inf")
+    x[3, -1] = float("-inf")
+    val, idx, lse = ops.topk_rows(x.to(dev()), 4)
+    ref = torch.logsumexp(x.float(), dim=-1)
+    assert torch.isfinite(lse).all()
+    assert torch.allclose(lse.cpu(), ref, rtol=1e-5, atol=1e-4)
+    tv, ti = torch.topk(x.float(), 4, dim=-1)
+    assert torch.equal(val[:, :4].cpu(), tv)

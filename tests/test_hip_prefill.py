@@ -250,3 +250,46 @@ def test_hf_prefill_is_still_selectable():
     H.assert_close("hf vs native prefill K", cb.k[2][:, :60], ca.k[2][:, :60], max_rel=H.KV_MAX_REL)
     with pytest.raises(NotImplementedError):
         NativeTarget(hf, prefill="hf", keep_hf=False)
+
+
+@pytest.mark.parametrize("P,n_q,n_kv", [(45, 4, 2), (300, 4, 4), (1024, 8, 2), (17, 2, 1)])
+def test_prefill_attention_matches_torch(P, n_q, n_kv):
+    """dfl_prefill_attn vs fp32 torch attention (causal, GQA) on random bf16 q / K / V rows: every query row, every head;
+    stale cache rows beyond P (NaN-poisoned here) must not leak in."""
+    from dflash_amd import ops
+    g = torch.Generator().manual_seed(P + n_q)
+    Pp = ops.prefill_rows_padded(P)
+    nqkv = (n_q + 2 * n_kv) * 128
+    qkv = torch.zeros(Pp, nqkv, dtype=BF16, device=dev())
+    qkv[:P, :n_q * 128] = torch.randn(P, n_q * 128, generator=g).to(BF16).to(dev())
+    kc = torch.full((n_kv, P + 40, 128), float("nan"), dtype=BF16, device=dev())
+    vc = torch.full_like(kc, float("nan"))
+    kc[:, :P] = torch.randn(n_kv, P, 128, generator=g).to(BF16).to(dev())
+    vc[:, :P] = torch.randn(n_kv, P, 128, generator=g).to(BF16).to(dev())
+    xf = torch.zeros(Pp * n_q * 128, dtype=BF16, device=dev())
+    ops.prefill_attn(qkv, P, 0, kc, vc, n_q, n_kv, 128 ** -0.5, xf)
+    got = _unpack_tiles(xf, P, n_q * 128).float().view(P, n_q, 128)
+    q = qkv[:P, :n_q * 128].float().view(P, n_q, 128).transpose(0, 1)                       # [n_q, P, 128]
+    k = kc[:, :P].float().repeat_interleave(n_q // n_kv, dim=0)
+    v = vc[:, :P].float().repeat_interleave(n_q // n_kv, dim=0)
+    sc = (q @ k.transpose(1, 2)) * 128 ** -0.5
+    sc = sc.masked_fill(torch.triu(torch.ones(P, P, dtype=torch.bool, device=dev()), 1), float("-inf"))
+    ref = (torch.softmax(sc, dim=-1) @ v).transpose(0, 1)                                  # [P, n_q, 128]
+    assert not torch.isnan(got).any()
+    H.assert_close(f"prefill attention P={P} heads {n_q}/{n_kv}", got, ref, max_rel=1e-2, mean_rel=1e-3)
+
+
+def test_prefill_sdpa_core_is_the_same_prefill():
+    """prefill_attn = "sdpa" (torch's attention on the rows the kernels produced) against the default k_pattn: logits
+    and K/V of the whole prefill agree."""
+    from dflash_amd import NativeTarget
+    from dflash_amd.synthetic import make_hf_qwen3
+    torch.manual_seed(11)
+    hf = make_hf_qwen3({**H.TINY_TARGET, "num_layers": 4}, dev())
+    a, b = NativeTarget(hf), NativeTarget(hf)
+    b.prefill_attn = "sdpa"
+    prompt = torch.randint(0, 2000, (1, 200), generator=torch.Generator().manual_seed(1)).to(dev())
+    ca, cb = a.new_cache(256), b.new_cache(256)
+    oa, ob = a.prefill(prompt, ca), b.prefill(prompt, cb)
+    H.assert_close("k_pattn vs sdpa prefill logits", oa.logits[0], ob.logits[0])
+    H.assert_close("k_pattn vs sdpa prefill K (last layer)", ca.k[3][:, :200], cb.k[3][:, :200], max_rel=H.KV_MAX_REL)
