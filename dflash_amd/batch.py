@@ -13,6 +13,8 @@ per-request preallocated KV caches, one device->host read of R x 4 ints.
 
 Needs the native target (`dflash_amd.NativeTarget`): the HF forward cannot take requests
 of different lengths without padding masks, which is exactly the cost this path removes.
+Sparse-MoE targets (round 3): attention and the dense projections run batched, the expert
+MLP per request (`BatchedDecoder._moe_mlp`).
 """
 from __future__ import annotations
 
@@ -52,8 +54,6 @@ class BatchedDecoder:
                  temperature: float = 0.0):
         if not isinstance(target, NativeTarget):
             raise TypeError("BatchedDecoder needs a dflash_amd.NativeTarget (see module docstring)")
-        if getattr(target, "is_moe", False):
-            raise NotImplementedError("the ragged batch runs dense targets; an MoE target decodes one request at a time")
         if not 1 <= n_requests <= MAX_GROUP:
             raise ValueError(f"a group holds 1..{MAX_GROUP} requests")
         if model.w is None:
@@ -100,7 +100,8 @@ class BatchedDecoder:
         self.nqkv_t = t.nqkv
         self.t = dict(h=z(MT, 16, H), ss_emb=z(MT, 16, dt=F32), xn=z(MT, 16 * H), attn=z(MT, 16 * t.q_dim),
                       act=z(MT, 16 * t.I), part_qkv=z(ks(H) * MT * 16 * t.nqkv, dt=F32),
-                      part_h=z(max(ks(t.q_dim), ks(t.I)) * MT * 16 * H, dt=F32))
+                      part_h=z(max(ks(t.q_dim), ks(t.I), getattr(t, "moe_nsplit", 0) if getattr(t, "is_moe", False) else 0)
+                               * MT * 16 * H, dt=F32))
         # ---- shared workspaces (launches are stream-ordered)
         nmax = max(c.vocab_size, t.V, 2 * I, 2 * t.I, self.nqkv_d, t.nqkv)
         kmax = max(H, I, t.I, c.fc_in, c.q_dim)
@@ -275,9 +276,10 @@ class BatchedDecoder:
             for a, b in dups:
                 taps[:, :, b * H:(b + 1) * H].copy_(taps[:, :, a * H:(a + 1) * H])
 
+        self._pend_ns = None   # part count of the pending sums when they are expert shares, not K parts
         for i, lw in enumerate(t.layers):
             ops.norm_frag_batch(tt["h"], R, lw["ln1"], t.eps, tt["xn"], self.dyn_t, ops.DYN_BS,
-                                part=tt["part_h"] if pend else None, N=H, K=pend, tap=ptap)
+                                part=tt["part_h"] if pend else None, N=H, K=pend, tap=ptap, nsplit=self._pend_ns)
             spread(pdup)
             if self.attn_impl == "head":
                 ops.gemm_resid_batch(lw["qkv"], s["xn"], R, t.nqkv, H, tt["xq"], add_residual=False, ws=self.gws,
@@ -298,15 +300,22 @@ class BatchedDecoder:
             ops.gemm_f32_batch(lw["o"], s["attn"], R, H, t.q_dim, tt["part_h"], self.dyn_t)
             ops.norm_frag_batch(tt["h"], R, lw["ln2"], t.eps, tt["xn"], self.dyn_t, ops.DYN_BS, part=tt["part_h"],
                                 N=H, K=t.q_dim)
-            ops.gemm_silu_mul_batch(lw["gu"], s["xn"], R, t.I, H, tt["act"], self.gws, self.dyn_t)
-            ops.gemm_f32_batch(lw["down"], s["act"], R, H, t.I, tt["part_h"], self.dyn_t)
+            pns = None
+            if "gu_e" in lw:   # sparse-MoE layer (Qwen3MoeSparseMoeBlock): the requests share attention and projections
+                pns = self._moe_mlp(lw)   # above; routing and expert weights are per request
+                pend = 1
+            else:
+                ops.gemm_silu_mul_batch(lw["gu"], s["xn"], R, t.I, H, tt["act"], self.gws, self.dyn_t)
+                ops.gemm_f32_batch(lw["down"], s["act"], R, H, t.I, tt["part_h"], self.dyn_t)
+                pend = t.I
             # the layer's output (a tapped layer's hidden rows, model/utils.py:16-25) exists once the
             # next norm launch has added these sums: it writes the tap
             sl = slots.get(i, ())
-            pend, ptap = t.I, (taps[:, :, sl[0] * H:(sl[0] + 1) * H] if sl else None)
+            ptap = taps[:, :, sl[0] * H:(sl[0] + 1) * H] if sl else None
             pdup = [(sl[0], b) for b in sl[1:]]
+            self._pend_ns = pns
         ops.norm_frag_batch(tt["h"], R, t.norm, t.eps, tt["xn"], self.dyn_t, ops.DYN_BS, part=tt["part_h"], N=H, K=pend,
-                            tap=ptap)
+                            tap=ptap, nsplit=self._pend_ns)
         spread(pdup)
         if self.temperature < 1e-5:
             ops.gemm_argmax_batch(self.lm_wp, s["xn"], R, t.V, H, 0, 16, self.gws, self.post, 0, self.dyn_t,
@@ -320,6 +329,32 @@ class BatchedDecoder:
             ops.gemm_argmax_batch(self.lm_wp, s["xn"], R, t.V, H, 0, 16, self.gws, self.post, 0, self.dyn_t,
                                   nrows_dyn_word=ops.DYN_BS, logits=self._logits)
             self.post[:R] = sample(self._logits[:R], self.temperature)
+
+    def _moe_mlp(self, lw: dict) -> int:
+        """Qwen3MoeSparseMoeBlock of one target layer for the requests of the group (tf:models/qwen3_moe/
+        modeling_qwen3_moe.py; the single-request form: NativeTarget._moe_mlp).  Attention and the dense projections of
+        the layer ran batched; here every request routes ITS rows (router GEMM on its ln2-normalised fragments, fp32
+        softmax / top-k / renormalise) and streams ITS active experts (gate/up + SiLU, routing-weighted down
+        projections) — the experts a request uses are its own, so there is no weight stream to share unless two
+        requests pick the same expert.  The routing-weighted sums land as fp32 shares in the batch's partial-sum
+        buffer, where the next norm launch adds them to the residual stream (one rounding).  Returns the share count."""
+        t, tt, R, MT, H = self.target, self.t, self.R, self.MT, self.cfg.hidden_size
+        w, ns = t.ws, t.moe_nsplit
+        part = tt["part_h"][:ns * MT * 16 * H].view(ns, MT * 16, H)
+        for r in range(R):
+            dt, xn = self.dyn_t[r], tt["xn"][r]
+            ops.gemm_resid(lw["router"], ops.rows_frag(xn), w["rlog"].shape[2], H, w["rlog"][0], add_residual=False, dyn=dt)
+            ops.moe_route(w["rlog"][0], t.E, t.top_k, t.norm_topk, w["wt"][0], w["active"], w["elist"], w["n_active"],
+                          dyn=dt, dyn_word=ops.DYN_BS)
+            if H <= 2048 and t.moe_pair_kernel:
+                ops.moe_gate_up(lw["gu_e"], xn, t.E, t.Ie, H, w["act_e"], w["elist"], w["n_active"], dyn=dt,
+                                valid_word=ops.DYN_BS)
+            else:
+                ops.gemm_silu_mul_experts(lw["gu_e"], ops.rows_frag(xn), t.E, t.Ie, H, w["act_e"], w["elist"],
+                                          w["n_active"], dyn=dt)
+            ops.moe_down(lw["down_e"], w["act_e"], w["wt"][0], w["elist"], w["n_active"], t.E, H, t.Ie, ns, w["moe_part"])
+            part[:, r * 16:(r + 1) * 16].copy_(w["moe_part"])
+        return ns
 
     def _accept_launch(self) -> None:
         ops.accept_commit_batch(self.block, self.post, self.R, self.output_ids, self.dyn_d, self.dyn_t, self.stop_t,

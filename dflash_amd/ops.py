@@ -561,7 +561,7 @@ def embed_rows_batch(embed, ids: torch.Tensor, R: int, h_out: torch.Tensor, H: i
 
 def norm_frag_batch(h: torch.Tensor, R: int, norm_w: torch.Tensor, eps: float, frag: torch.Tensor, dyn,
                     dyn_word: int, part: Optional[torch.Tensor] = None, N: int = 0, K: int = 0,
-                    tap: Optional[torch.Tensor] = None) -> None:
+                    tap: Optional[torch.Tensor] = None, nsplit: Optional[int] = None) -> None:
     """h [MT, 16, H] -> frag [MT, 16*H] = frag16 of the RMS-normalised rows.  part: the fp32
     partial sums gemm_f32_batch(N=H, K) left ([ksplit][MT*16][H]): added to h first (residual
     add, in place); tap: optional [MT, 16, *] view receiving the new rows."""
@@ -569,8 +569,8 @@ def norm_frag_batch(h: torch.Tensor, R: int, norm_w: torch.Tensor, eps: float, f
     H = h.shape[2]
     pp, ns, ps, ldp = None, 0, 0, 0
     if part is not None:
-        assert N == H and K > 0
-        ns, ldp = batch_ksplit(K), N
+        assert N == H and (K > 0 or nsplit)
+        ns, ldp = (nsplit if nsplit else batch_ksplit(K)), N   # nsplit: partial sums that are not a K split (MoE expert shares)
         ps = batch_tiles(R) * 16 * N
         assert part.numel() >= ns * ps
         pp = _p(part, F32, "part")

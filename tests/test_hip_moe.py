@@ -329,3 +329,44 @@ def test_native_moe_target_end_to_end_lossless_walk():
                                 max_new_tokens=n_new, stop_token_ids=None, temperature=0.0, scheduler=sched2,
                                 draft_token_hook=hook24)
     assert rq.output_ids[0].tolist() == G[:30 + n_new].tolist() and max(rq.used_block_sizes) > 16
+
+
+def test_moe_target_in_the_ragged_batch():
+    """An MoE target under dflash_generate_batch (round 3: attention and dense projections of the group in one pass over
+    the weights, the expert MLP per request): every request's committed ids are the target's greedy walk and equal the
+    single-request loop's, acceptance lengths included."""
+    from dflash_amd import DFlashDraftModel, NativeTarget, dflash_generate
+    from dflash_amd.batch import dflash_generate_batch
+    from dflash_amd.synthetic import greedy_walk, impose_greedy_walk
+    cfg = H.tiny_cfg(num_target_layers=4, target_layer_ids=[0, 2])
+    m = DFlashDraftModel(cfg, device=dev())
+    m.load_state_dict(H.draft_weights(cfg, dtype=BF16))
+    hf = _moe_hf(mlp_only=(1,))          # three MoE layers and a dense one in between
+    perm = impose_greedy_walk(hf, seed=5)
+    nt = NativeTarget(hf)
+    lens, n_new = (30, 47, 12), 50
+    prompts = [torch.randint(0, 2000, (1, P), generator=torch.Generator().manual_seed(60 + i)).to(dev())
+               for i, P in enumerate(lens)]
+    Gs = [greedy_walk(perm, p, n_new + 40).to(dev()) for p in prompts]
+    plans = [H.make_plan(64, 16, 41 + i) for i in range(len(lens))]
+
+    def hook_for(i):
+        def hook(blk, start, call):
+            k = min(plans[i][call], blk.shape[1] - 1)
+            blk[0, 1:k + 1] = Gs[i][start + 1:start + k + 1]
+            if k + 1 < blk.shape[1]:
+                w = Gs[i][start + k + 1]
+                blk[0, k + 1] = torch.where(blk[0, k + 1] == w, (w + 1) % 2000, blk[0, k + 1])
+        return hook
+
+    hooks = [hook_for(i) for i in range(len(lens))]
+    singles = [dflash_generate(m, nt, prompts[i], cfg.mask_token_id, n_new, 16, None, 0.0, draft_token_hook=hooks[i])
+               for i in range(len(lens))]
+
+    def bhook(i, blk, start, call):
+        hooks[i](blk[:, :min(16, lens[i] + n_new - start)], start, call)
+
+    outs = dflash_generate_batch(m, nt, prompts, cfg.mask_token_id, n_new, 16, None, 0.0, draft_token_hook=bhook)
+    for i, (a, b) in enumerate(zip(singles, outs)):
+        assert b.output_ids[0].tolist() == a.output_ids[0].tolist() == Gs[i][:lens[i] + n_new].tolist(), f"request {i}"
+        assert b.acceptance_lengths == a.acceptance_lengths, f"request {i}"
