@@ -331,30 +331,8 @@ class BatchedDecoder:
             self.post[:R] = sample(self._logits[:R], self.temperature)
 
     def _moe_mlp(self, lw: dict) -> int:
-        """Qwen3MoeSparseMoeBlock of one target layer for the requests of the group (tf:models/qwen3_moe/
-        modeling_qwen3_moe.py; the single-request form: NativeTarget._moe_mlp).  Attention and the dense projections of
-        the layer ran batched; here every request routes ITS rows (router GEMM on its ln2-normalised fragments, fp32
-        softmax / top-k / renormalise) and streams ITS active experts (gate/up + SiLU, routing-weighted down
-        projections) — the experts a request uses are its own, so there is no weight stream to share unless two
-        requests pick the same expert.  The routing-weighted sums land as fp32 shares in the batch's partial-sum
-        buffer, where the next norm launch adds them to the residual stream (one rounding).  Returns the share count."""
-        t, tt, R, MT, H = self.target, self.t, self.R, self.MT, self.cfg.hidden_size
-        w, ns = t.ws, t.moe_nsplit
-        part = tt["part_h"][:ns * MT * 16 * H].view(ns, MT * 16, H)
-        for r in range(R):
-            dt, xn = self.dyn_t[r], tt["xn"][r]
-            ops.gemm_resid(lw["router"], ops.rows_frag(xn), w["rlog"].shape[2], H, w["rlog"][0], add_residual=False, dyn=dt)
-            ops.moe_route(w["rlog"][0], t.E, t.top_k, t.norm_topk, w["wt"][0], w["active"], w["elist"], w["n_active"],
-                          dyn=dt, dyn_word=ops.DYN_BS)
-            if H <= 2048 and t.moe_pair_kernel:
-                ops.moe_gate_up(lw["gu_e"], xn, t.E, t.Ie, H, w["act_e"], w["elist"], w["n_active"], dyn=dt,
-                                valid_word=ops.DYN_BS)
-            else:
-                ops.gemm_silu_mul_experts(lw["gu_e"], ops.rows_frag(xn), t.E, t.Ie, H, w["act_e"], w["elist"],
-                                          w["n_active"], dyn=dt)
-            ops.moe_down(lw["down_e"], w["act_e"], w["wt"][0], w["elist"], w["n_active"], t.E, H, t.Ie, ns, w["moe_part"])
-            part[:, r * 16:(r + 1) * 16].copy_(w["moe_part"])
-        return ns
+        """Sparse-MoE MLP of one target layer for the requests of the group: NativeTarget.moe_mlp_tiles."""
+        return self.target.moe_mlp_tiles(lw, self.R, self.MT, self.dyn_t, self.t["xn"], self.t["part_h"])
 
     def _accept_launch(self) -> None:
         ops.accept_commit_batch(self.block, self.post, self.R, self.output_ids, self.dyn_d, self.dyn_t, self.stop_t,

@@ -211,8 +211,6 @@ class NativeCandidateVerifier:
         from .target import NativeTarget
         if not isinstance(target, NativeTarget):
             raise TypeError("NativeCandidateVerifier needs a dflash_amd.NativeTarget")
-        if getattr(target, "is_moe", False):
-            raise NotImplementedError("the one-pass candidate verify runs dense targets")
         t, MT = target, self.MT
         self.t, self.max_splits = t, max_splits
         dev = t.device
@@ -223,7 +221,7 @@ class NativeCandidateVerifier:
         self.h, self.ss_emb = z(MT, 16, H), z(MT, 16, dt=F32)
         self.xn, self.attn, self.act = z(MT, 16 * H), z(MT, 16 * t.q_dim), z(MT, 16 * t.I)
         self.xq = z(MT, 16, t.nqkv)
-        self.part_h = z(max(ks(t.q_dim), ks(t.I)) * MT * 16 * H, dt=F32)
+        self.part_h = z(max(ks(t.q_dim), ks(t.I), t.moe_nsplit if getattr(t, "is_moe", False) else 0) * MT * 16 * H, dt=F32)
         nmax, kmax = max(t.V, 2 * t.I, t.nqkv), max(H, t.I, t.q_dim)
         self.gws = torch.zeros(max(ops.lib().dfl_gemm_batch_ws_bytes(n, k) for n, k in ((nmax, H), (H, kmax))),
                                dtype=torch.uint8, device=dev)
@@ -264,9 +262,10 @@ class NativeCandidateVerifier:
             for a, b in dups:
                 self.taps[:, :, b * H:(b + 1) * H].copy_(self.taps[:, :, a * H:(a + 1) * H])
 
+        pns = None   # share count of the pending sums when they are MoE expert shares, not K parts
         for i, lw in enumerate(t.layers):
             ops.norm_frag_batch(self.h, R, lw["ln1"], t.eps, self.xn, dyn, ops.DYN_BS,
-                                part=self.part_h if pend else None, N=H, K=pend, tap=ptap)
+                                part=self.part_h if pend else None, N=H, K=pend, tap=ptap, nsplit=pns)
             spread(pdup)
             ops.gemm_resid_batch(lw["qkv"], s["xn"], R, t.nqkv, H, self.xq, add_residual=False, ws=self.gws, dyn=dyn)
             ops.attn_head_cand(xq=self.xq[:C], q_col=0, k_col=t.q_dim, v_col=t.q_dim + t.kv_dim, n_q=t.n_q, n_kv=t.n_kv,
@@ -276,12 +275,17 @@ class NativeCandidateVerifier:
                                k_out=self.stage_k[i], v_out=self.stage_v[i])
             ops.gemm_f32_batch(lw["o"], s["attn"], R, H, t.q_dim, self.part_h, dyn)
             ops.norm_frag_batch(self.h, R, lw["ln2"], t.eps, self.xn, dyn, ops.DYN_BS, part=self.part_h, N=H, K=t.q_dim)
-            ops.gemm_silu_mul_batch(lw["gu"], s["xn"], R, t.I, H, self.act, self.gws, dyn)
-            ops.gemm_f32_batch(lw["down"], s["act"], R, H, t.I, self.part_h, dyn)
+            if "gu_e" in lw:   # sparse-MoE layer: every candidate routes its own rows (round 3)
+                pns, pend = t.moe_mlp_tiles(lw, R, MT, dyn, self.xn, self.part_h), 1
+            else:
+                ops.gemm_silu_mul_batch(lw["gu"], s["xn"], R, t.I, H, self.act, self.gws, dyn)
+                ops.gemm_f32_batch(lw["down"], s["act"], R, H, t.I, self.part_h, dyn)
+                pns, pend = None, t.I
             sl = slots.get(i, ())
-            pend, ptap = t.I, (self.taps[:, :, sl[0] * H:(sl[0] + 1) * H] if sl else None)
+            ptap = self.taps[:, :, sl[0] * H:(sl[0] + 1) * H] if sl else None
             pdup = [(sl[0], b) for b in sl[1:]]
-        ops.norm_frag_batch(self.h, R, t.norm, t.eps, self.xn, dyn, ops.DYN_BS, part=self.part_h, N=H, K=pend, tap=ptap)
+        ops.norm_frag_batch(self.h, R, t.norm, t.eps, self.xn, dyn, ops.DYN_BS, part=self.part_h, N=H, K=pend, tap=ptap,
+                            nsplit=pns)
         spread(pdup)
         ops.gemm_argmax_batch(t.lm_wp, s["xn"], R, t.V, H, 0, 16, self.gws, self.post, 0, dyn, nrows_dyn_word=ops.DYN_BS)
         return self.post[:C, :bs]

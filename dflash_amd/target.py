@@ -383,6 +383,33 @@ class NativeTarget:
                           part_split=16 * H, ldp=H, resid_in=hrow[t], h_out=hrow[t], h_out2=tap,
                           ld2=taps.stride(0) if tap is not None else 0, dyn=dt, dyn_word=ops.DYN_BS)
 
+    def moe_mlp_tiles(self, lw: dict, R: int, MT: int, dyn: torch.Tensor, xn: torch.Tensor, part: torch.Tensor) -> int:
+        """Qwen3MoeSparseMoeBlock (tf:models/qwen3_moe/modeling_qwen3_moe.py) of one layer for R 16-row tiles that went
+        through the layer's attention and dense projections together (requests of a ragged batch, candidate blocks of
+        one verify): tile r routes ITS rows — router GEMM on its ln2-normalised fragments xn[r], fp32 softmax / top-k /
+        renormalise — and streams ITS active experts (gate/up + SiLU, routing-weighted down projections); the experts a
+        tile uses are its own, so there is no weight stream to share unless two tiles pick the same expert.  The
+        routing-weighted sums land as fp32 shares in the batch partial-sum layout part[share][MT * 16][H], where the
+        next dfl_norm_frag_batch adds them to the residual stream (one rounding).  dyn: [MT, 8] length records (valid
+        rows = the DYN_BS word).  Returns the share count."""
+        w, ns, H = self.ws, self.moe_nsplit, self.H
+        pv = part[:ns * MT * 16 * H].view(ns, MT * 16, H)
+        for r in range(R):
+            dt, x = dyn[r], xn[r]
+            ops.gemm_resid(lw["router"], ops.rows_frag(x), w["rlog"].shape[2], H, w["rlog"][0], add_residual=False, dyn=dt)
+            ops.moe_route(w["rlog"][0], self.E, self.top_k, self.norm_topk, w["wt"][0], w["active"], w["elist"],
+                          w["n_active"], dyn=dt, dyn_word=ops.DYN_BS)
+            if H <= 2048 and self.moe_pair_kernel:
+                ops.moe_gate_up(lw["gu_e"], x, self.E, self.Ie, H, w["act_e"], w["elist"], w["n_active"], dyn=dt,
+                                valid_word=ops.DYN_BS)
+            else:
+                ops.gemm_silu_mul_experts(lw["gu_e"], ops.rows_frag(x), self.E, self.Ie, H, w["act_e"], w["elist"],
+                                          w["n_active"], dyn=dt)
+            ops.moe_down(lw["down_e"], w["act_e"], w["wt"][0], w["elist"], w["n_active"], self.E, H, self.Ie, ns,
+                         w["moe_part"])
+            pv[:, r * 16:(r + 1) * 16].copy_(w["moe_part"])
+        return ns
+
     # ---- the verify forward on the kernels
     def _verify_wide(self, block_ids, start, cache, bs, tap_layers, taps, logits_out, temperature, cos, sin):
         """Blocks of 17..32 rows in ONE pass over the weights: the two 16-row tiles go through the ragged-batch
