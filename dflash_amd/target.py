@@ -423,7 +423,8 @@ class NativeTarget:
             nmax, kmax = max(self.V, 2 * self.I, self.nqkv), max(H, self.I, self.q_dim)
             self._wide = dict(
                 xn=xn, ids=torch.zeros(2, 16, dtype=torch.int64, device=dev),
-                part_h=torch.zeros(max(ks(self.q_dim), ks(self.I)) * 2 * 16 * H, dtype=torch.float32, device=dev),
+                part_h=torch.zeros(max(ks(self.q_dim), ks(self.I), self.moe_nsplit if self.is_moe else 0) * 2 * 16 * H,
+                                   dtype=torch.float32, device=dev),
                 gws=torch.zeros(max(ops.lib().dfl_gemm_batch_ws_bytes(n, k) for n, k in ((nmax, H), (H, kmax))),
                                 dtype=torch.uint8, device=dev),
                 src=dict(xn=ops.brows_frag(xn), attn=ops.brows_frag(ws["attn"]), act=ops.brows_frag(ws["act"])))
@@ -443,9 +444,10 @@ class NativeTarget:
             for a, b in dups:
                 taps[:, b * H:(b + 1) * H].copy_(taps[:, a * H:(a + 1) * H])
 
+        pns = None   # share count of the pending sums when they are MoE expert shares, not K parts
         for i, lw in enumerate(self.layers):
             ops.norm_frag_batch(h3, R, lw["ln1"], self.eps, xn, dyn2, ops.DYN_BS, part=part_h if pend else None, N=H,
-                                K=pend, tap=ptap)
+                                K=pend, tap=ptap, nsplit=pns)
             spread(pdup)
             ops.gemm_resid_batch(lw["qkv"], s["xn"], R, self.nqkv, H, xq3, add_residual=False, ws=gws, dyn=dyn2)
             ops.attn_head(xq=ws["xq"], q_col=0, k_col=self.q_dim, v_col=self.q_dim + self.kv_dim, n_q=self.n_q,
@@ -455,12 +457,17 @@ class NativeTarget:
                           q_tiles=2, out_tile_stride=ws["attn"].stride(0))
             ops.gemm_f32_batch(lw["o"], s["attn"], R, H, self.q_dim, part_h, dyn2)
             ops.norm_frag_batch(h3, R, lw["ln2"], self.eps, xn, dyn2, ops.DYN_BS, part=part_h, N=H, K=self.q_dim)
-            ops.gemm_silu_mul_batch(lw["gu"], s["xn"], R, self.I, H, ws["act"], gws, dyn2)
-            ops.gemm_f32_batch(lw["down"], s["act"], R, H, self.I, part_h, dyn2)
+            if "gu_e" in lw:   # sparse-MoE layer: each of the two tiles routes its own rows (round 3)
+                pns, pend = self.moe_mlp_tiles(lw, R, 2, dyn2, xn, part_h), 1
+            else:
+                ops.gemm_silu_mul_batch(lw["gu"], s["xn"], R, self.I, H, ws["act"], gws, dyn2)
+                ops.gemm_f32_batch(lw["down"], s["act"], R, H, self.I, part_h, dyn2)
+                pns, pend = None, self.I
             sl = slots.get(i, ())   # a tapped layer's rows exist once the next norm launch has added these sums
-            pend, ptap = self.I, (tap3[:, :, sl[0] * H:(sl[0] + 1) * H] if sl else None)
+            ptap = tap3[:, :, sl[0] * H:(sl[0] + 1) * H] if sl else None
             pdup = [(sl[0], b) for b in sl[1:]]
-        ops.norm_frag_batch(h3, R, self.norm, self.eps, xn, dyn2, ops.DYN_BS, part=part_h, N=H, K=pend, tap=ptap)
+        ops.norm_frag_batch(h3, R, self.norm, self.eps, xn, dyn2, ops.DYN_BS, part=part_h, N=H, K=pend, tap=ptap,
+                            nsplit=pns)
         spread(pdup)
         post = ws["post"]
         logits = logits_out
@@ -488,8 +495,8 @@ class NativeTarget:
         taps_out: the caller's own [32, len(tap_layers)*H] buffer (a decode session keeps the
         rows until its next draft; sessions interleaved on one target must not share one).
         logits_out: bf16 [16 * tiles, V].  Blocks of 17..32 rows run as two 16-row tiles: one pass over the
-        weights through the ragged-batch GEMMs (`_verify_wide`; dense targets), or one launch per tile of every
-        single-request GEMM (wide_one_pass = False, MoE targets); both query tiles share the attention launch."""
+        weights through the ragged-batch GEMMs (`_verify_wide`; an MoE layer's expert MLP per tile), or one launch per
+        tile of every single-request GEMM (wide_one_pass = False); both query tiles share the attention launch."""
         bs = block_ids.numel()
         if bs < 1 or bs > 32:
             raise ValueError("verify takes 1..32 block rows")
@@ -524,7 +531,7 @@ class NativeTarget:
                     self._taps[key] = torch.zeros(32, key * H, dtype=BF16, device=self._dev)
                 taps = self._taps[key]
         Ls, src = self.layers, self.src
-        if len(tiles) == 2 and self.wide_one_pass and not self.is_moe and self.attn_impl == "head":
+        if len(tiles) == 2 and self.wide_one_pass and self.attn_impl == "head":
             return self._verify_wide(block_ids, start, cache, bs, tap_layers, taps, logits_out, temperature, cos, sin)
         hrow = [ws["h"][16 * t:16 * t + 16] for t in range(2)]
         for t, dt in tiles:
