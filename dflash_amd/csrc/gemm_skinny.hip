@@ -79,45 +79,31 @@ __device__ unsigned long long g_wgstamps[256][4];
 #define GSTAMP(i)
 #endif
 
-#ifndef DFL_EARLY_B   // A/B switch: 0 = item 1's weights are requested at the top of the loop (round 2), not in the prologue
-#define DFL_EARLY_B 0
-#endif
-#ifndef DFL_NORM_OWN  // A/B switch: 0 = a normalised source's sums of squares come from the producer's partials (round 2)
-#define DFL_NORM_OWN 0
-#endif
-#ifndef DFL_RAW_BARRIER  // A/B switch: 1 = a workgroup barrier between the issue of the rows' loads and the first weight request
-#define DFL_RAW_BARRIER 1
-#endif
-#ifndef DFL_NORM_WAIT  // A/B switch (scripts/ab_prof.sh): 0 = a normalised source's rows are not waited for before the weights
-#define DFL_NORM_WAIT 0
-#endif
-
 constexpr int gemm_fr(int MT, bool CHUNKED) { return CHUNKED ? 4 : (MT == 1 ? 8 : 4); }
 
 // One launch.  Order of the prologue (round 3; measured with scripts/dbg_gemm_stamps.py, scripts/ab_prof.sh and against
 // the pure-stream floor of scripts/probes/l2_prefetch_probe.hip — a stream of the same bytes in the same four launches
 // per layer takes 62 us where the round-2 kernels took 80):
-//   1. the activation side first: the wave's row fragments (8 KB, from L2) and, for a normalised source, one chunk of
-//      the RMSNorm weight (staged ONCE per workgroup in LDS instead of 32 VGPRs per lane).  Their addresses need the
-//      head of the argument block and the lane number only — no length (dependent scalar load) sits in front of them.
-//      A wave's vector loads return in issue order and, at a launch's start, everything requested behind the first
-//      weight burst queues behind ~32-64 MB in the memory system: asked for first, the rows are back after ~1.5 us and
-//      the sum of squares -> rstd -> normalise chain (1-2 us of VALU on 16 waves) runs UNDER the weight latency.
-//      (Tried the other way round, weights first: the rows came back 8 us later and the chain ran with HBM idle —
-//      gate/up 34.8 -> 36.6 us, qkv 14.3 -> 16.4 us in the cycle.)
-//   2. then item 0's weights, the residual value of the first tile, and item 1's weights — all BEFORE anything is
-//      waited for, so that two items are in flight while the chain runs;
-//   3. a normalised source's sum of squares is computed by the workgroup ITSELF from the rows it has just loaded
-//      (v_dot2c_f32_bf16; the whole K is in the workgroup): round 2 loaded the producer's per-tile partial sums, a
-//      dependent load that came back 5.6 us after its request with the burst already under way;
-//   4. only then the waits: lengths (scalar), rstd across the 16 waves, normalise, and the item loop.
+//   0. the lengths (dyn words): dependent SCALAR loads.  Requested behind the first weight burst they came back 5 - 9 us
+//      later — most of what round 2 called the "rstd prologue".  Asked for before any vector load they cost nothing.
+//   1. the activation side: the wave's row fragments (8 KB, from L2), for a normalised source one chunk of the RMSNorm
+//      weight (staged ONCE per workgroup in LDS instead of 32 VGPRs per lane) and the producer's partial sums of
+//      squares.  A wave's vector loads return in issue order and, at a launch's start, everything requested behind the
+//      first weight burst queues behind ~32-64 MB in the memory system: asked for first, the rows are back after
+//      ~1.5 us and the sum of squares -> rstd -> normalise chain (1-2 us of VALU on 16 waves) runs UNDER the weight
+//      latency.  (Weights first: the rows came back 8 us later and the chain ran with HBM idle — gate/up 34.8 -> 36.6 us,
+//      qkv 14.3 -> 16.4 us in the cycle.)  Launches without a normalised source put a workgroup barrier here, so that
+//      every wave's row requests are in the CU's in-order memory pipe before any wave's weight request.
+//   2. then item 0's weights and (residual launches without a norm) the residual value of the first tile;
+//   3. only then the waits: rstd across the 16 waves, normalise, and the item loop (item i+1 requested at its top).
 // Every load of the prologue is unconditional (clamped addresses, zero-length descriptors): a load under a branch
 // costs a vmcnt(0) at the join, i.e. the whole burst.
-// NORM = 1: the workgroup sees the whole K (gridDim.y == 1), so it sums the squares of the rows it has just loaded
-// ITSELF — no dependent load at all: the partial sums of squares a producer left in memory came back 5.6 - 8 us after
-// their request (queued behind every CU's first weight burst), with HBM idle behind them.  NORM = 2: K is cut over
-// grid.y (fp32-partial launches of the round-1 attention path): the row sums come from the producer's partials.
-template <int MT, bool CHUNKED, int EPI, int NORM>
+// NORM: the launch has a normalised source (mode 2); the other instantiation carries none of that code or its LDS.
+// Variants built, measured on the same box and dropped (DESIGN.md section 5 has the numbers; the code is in the history,
+// commits dc953f3 and 5c920f1): item 1's weights requested in the prologue as well; the workgroup summing the squares
+// of its own rows (v_dot2c) instead of loading the producer's partials; waiting for the rows before the first weight
+// request; an 8-wave, three-buffer form of the K-chunked kernel.
+template <int MT, bool CHUNKED, int EPI, bool NORM>
 __device__ __forceinline__ void gemm_body(const GemmArgs &a) {
   GSTAMP(0);
   constexpr int FR = gemm_fr(MT, CHUNKED);
@@ -332,8 +318,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &a) {
                                      : (s.mode == 0 ? reinterpret_cast<const char *>(s.frag) : reinterpret_cast<const char *>(s.rows));
         nwv[mt] = *reinterpret_cast<const bf16x8 *>(nb + c * 16);
       }
-      if (NORM && s.mode == 2) any_norm = true;
-      if (NORM == 2 && s.mode == 2) {  // uniform (a kernel argument); the loads inside are clamped, not guarded
+      if (NORM && s.mode == 2) {  // uniform (a kernel argument); the loads inside are clamped, not guarded
         // the nss partial sums of squares of a row are summed by the 16 waves together:
         // wave w takes partials w, w+16, ... (four loads in flight per lane per 256)
         const int m = l & 15, part = l >> 4;
@@ -342,6 +327,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &a) {
           const int i = w + 16 * (part + 4 * u);
           ssv[mt][u] = s.ss[(i < s.nss ? i : s.nss - 1) * 16 + m];
         }
+        any_norm = true;
       }
     }
     int ks[FR];
@@ -359,41 +345,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &a) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) issue_x<FR, false>(a.src[mt], ks, l, 16, raw[mt], wv0[mt]);
     __builtin_amdgcn_sched_barrier(0);  // the ORDER of issue is the point: hipcc moved the weight requests in front
-    if (DFL_RAW_BARRIER && NORM == 0) {  // every wave's row requests enter the CU's in-order memory pipe before any weight request
+    if (!NORM) {  // every wave's row requests enter the CU's in-order memory pipe before any weight request
       __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    auto own_ss = [&]() {  // NORM == 1: norm weight chunk and this wave's sums of squares -> LDS (waits for the rows)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const RowSrc &s = a.src[mt];
-        nwl[mt][tid & 511] = nwv[mt];
-        if (NORM == 1 && s.mode == 2) {  // this wave's share of the rows' sums of squares, from the fragments themselves
-          const int m = l & 15, part = l >> 4;
-          float t0 = 0.f, t1 = 0.f;  // v_dot2c_f32_bf16: two squares per instruction, no conversions, fp32 sums
-#pragma unroll
-          for (int f = 0; f < FR; ++f) {
-            const bf16x8 r = raw[mt][f];
-            float q0 = 0.f, q1 = 0.f;
-            q0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(r, r, 0, 1), __builtin_shufflevector(r, r, 0, 1), q0, false);
-            q1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(r, r, 2, 3), __builtin_shufflevector(r, r, 2, 3), q1, false);
-            q0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(r, r, 4, 5), __builtin_shufflevector(r, r, 4, 5), q0, false);
-            q1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(r, r, 6, 7), __builtin_shufflevector(r, r, 6, 7), q1, false);
-            t0 += take[f] ? q0 : 0.f;
-            t1 += take[f] ? q1 : 0.f;
-          }
-          float t = t0 + t1;
-          t += __shfl_xor(t, 16, 64);
-          t += __shfl_xor(t, 32, 64);
-          if (part == 0) ssred[mt][w][m] = t;
-        }
-      }
-    };
-    if (NORM == 1 && DFL_NORM_WAIT) {
-      // A normalised source WAITS for its rows here, before the first weight request: once any CU's burst is under
-      // way every load queues behind tens of MB, and all 16 waves meet at the barrier below.  One unloaded round trip
-      // (~1.2 us) now; the barrier / rstd / normalise chain then runs under the weights' latency.
-      own_ss();
       __builtin_amdgcn_sched_barrier(0);
     }
     // ---- (2) item 0's weights.  No guards on the k-step count anywhere: a runtime guard makes hipcc branch around
@@ -409,24 +362,14 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &a) {
     GSTAMP(6);
     __builtin_amdgcn_sched_barrier(0);
     ask_resid0();
-    // ---- (3) item 1's weights (a zero-length descriptor when the workgroup has a single item)
-    if (NORM == 1 && DFL_EARLY_B == 2 && !DFL_NORM_WAIT) {
-      own_ss();  // waits for the rows (asked for before the weights): item 1 is requested once they are back
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (!moe && DFL_EARLY_B) {  // (the expert-list launch keeps item 1 for the loop: its tile index is another dependent scalar load)
-      const int t1 = nitems > 1 ? tile_of(1) : 0;
-      load_ksteps<FR>(wB, a.wp + ((size_t)t1 * a.KS + ks0_of(0)) * 64, nitems > 1 ? nf0 : 0, l, half_of(1));
-    }
     GSTAMP(1);
-    // ---- (4) rstd, normalise
-    if (NORM == 1 && !DFL_NORM_WAIT && DFL_EARLY_B != 2) own_ss();
+    // ---- (3) rstd, normalise
     if (NORM && any_norm) {  // uniform over the workgroup: the modes are kernel arguments
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const RowSrc &s = a.src[mt];
-        if (NORM == 2) nwl[mt][tid & 511] = nwv[mt];  // both halves of the workgroup store the same 512 chunks
-        if (NORM == 2 && s.mode == 2) {
+        if (NORM) nwl[mt][tid & 511] = nwv[mt];  // both halves of the workgroup store the same 512 chunks
+        if (NORM && s.mode == 2) {
           const int m = l & 15, part = l >> 4;
           float v[4];
 #pragma unroll
@@ -485,10 +428,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &a) {
         cn = 0;
         ++jn;
       }
-      // (the single-chunk kernels requested item 1 in the prologue)
       // (requesting unconditionally — a zero-length dummy past the last item, so that hipcc can count the loads in
       // flight — was tried twice in this 16-wave kernel, rounds 2 and 3: 20.4 -> 20.8 us on down_proj; not kept)
-      if (i + 1 < nitems && (CHUNKED || moe || !DFL_EARLY_B || i > 0)) load_item(wB, xB, tile_of(jn), cn, half_of(jn));
+      if (i + 1 < nitems) load_item(wB, xB, tile_of(jn), cn, half_of(jn));
       process(wA, xA, tile_of(j), c, j);
       if (i == 0) GSTAMP(4);
       if (i + 1 >= nitems) break;
@@ -529,123 +471,23 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &a) {
   }
 }
 
-template <int MT, bool CHUNKED, int EPI, int NORM>
+template <int MT, bool CHUNKED, int EPI, bool NORM>
 __global__ __launch_bounds__(1024) void k_gemm(GemmArgs a) {
   gemm_body<MT, CHUNKED, EPI, NORM>(a);
 }
-
-// ---- K-chunked residual GEMM, second form (round 3): 8 waves x 8 k-steps per item and THREE rotating buffers.
-// The 16-wave form above holds two 64 KB items per workgroup at 128 VGPRs (one in flight while one is in the MFMAs);
-// a 512-thread workgroup alone on a CU gives each wave 256 VGPRs: three weight buffers + three activation buffers
-// (192 VGPRs), i.e. TWO items = 128 KB per CU in flight while the third is in the MFMAs.  Every request is
-// unconditional (a zero-length descriptor past the last item) and pinned in front of the MFMAs, as in gemm_batch.hip:
-// with 8 waves per CU a wave's own pipelining matters.  Plain / fragment row sources only (mode 0 / 1); one LDS
-// meeting per TILE (the K chunks of a tile accumulate in registers).  down_proj and the draft's fc.
-template <int DUMMY>
-__global__ __launch_bounds__(512) void k_gemm_chunk8(GemmArgs a) {
-  constexpr int FR = 8, NW = 8;
-  __shared__ float red[2][NW][256];
-  const int tid = threadIdx.x;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l = tid & 63;
-  const RowSrc &src = a.src[0];
-  const int nv = (src.valid_word >= 0 && a.dyn) ? a.dyn[src.valid_word] : 16;  // asked for before any vector load
-  __builtin_amdgcn_sched_barrier(0);
-  const int stride = gridDim.x;
-  const int nseq = (int)blockIdx.x < a.ntiles ? (a.ntiles - 1 - (int)blockIdx.x) / stride + 1 : 0;
-  const int nitems = nseq * a.nch;
-  auto ks0_of = [&](int c) { return (c * NW + w) * FR; };
-  auto nf_of = [&](int c) {
-    const int nf = a.KS - ks0_of(c);
-    return nf < 0 ? 0 : (nf > FR ? FR : nf);
-  };
-  bf16x8 wA[FR], wB[FR], wC[FR], xA[FR], xB[FR], xC[FR];
-  // item i = (tile blockIdx.x + (i / nch) * stride, chunk i % nch); live = false: a dummy (no weight traffic; the
-  // activation fragments of the last real chunk once more, from L2)
-  auto load_item = [&](bf16x8(&wr)[FR], bf16x8(&xr)[FR], int i, bool live) {
-    const int ii = live ? i : (nitems > 0 ? nitems - 1 : 0);
-    const int t = (int)blockIdx.x + (ii / a.nch) * stride, c = ii % a.nch;
-    load_ksteps<FR>(wr, a.wp + ((size_t)t * a.KS + ks0_of(c)) * 64, live ? nf_of(c) : 0, l);
-    int ks[FR];
-#pragma unroll
-    for (int f = 0; f < FR; ++f) ks[f] = ks0_of(c) + f < a.KS ? ks0_of(c) + f : a.KS - 1;
-    bf16x8 wv[FR];
-#pragma unroll
-    for (int f = 0; f < FR; ++f) wv[f] = xr[f] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-    issue_x<FR, false>(src, ks, l, nv, xr, wv);
-  };
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  bf16_t resid0 = (bf16_t)0.f;
-  auto process = [&](bf16x8(&wr)[FR], bf16x8(&xr)[FR], int i) {
-    const int pos = i / a.nch, c = i - pos * a.nch, t = (int)blockIdx.x + pos * stride;
-    if (c == 0) acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int ks0c = ks0_of(c);
-#pragma unroll
-    for (int f = 0; f < FR; ++f) {
-      const bool keep = ks0c + f < a.KS && (src.mode == 0 || (l & 15) < nv);
-      const bf16x8 xv = keep ? xr[f] : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[f], xv, acc, 0, 0, 0);
-    }
-    if (c != a.nch - 1) return;
-    const int buf = pos & 1;
-    *reinterpret_cast<f32x4 *>(&red[buf][w][l * 4]) = acc;
-    __syncthreads();
-    if (tid < 256) {  // row m = tid >> 4, column nl = tid & 15 of the tile (D layout as in gemm_body)
-      const int m = tid >> 4, nl = tid & 15;
-      const int idx = 4 * (m + 16 * (nl >> 2)) + (nl & 3);
-      float sum = 0.f;
-#pragma unroll
-      for (int ww = 0; ww < NW; ++ww) sum += red[buf][ww][idx];
-      const int n = t * 16 + nl;
-      const float v = rbf(sum);
-      bf16_t *hp = a.h_io + (int64_t)m * a.ldh + n;
-      float hn = v;
-      if (a.add_resid) hn = rbf(bf2f(pos == 0 ? resid0 : *hp) + v);
-      *hp = f2bf(hn);
-      if (a.tap) a.tap[(int64_t)m * a.ldtap + n] = f2bf(hn);
-      const float q = row_sum16(hn * hn);
-      if (nl == 0 && a.ss_out) a.ss_out[t * 16 + m] = q;
-    }
-  };
-  // prologue: two items leave, then the first tile's residual value (every thread asks: no branch around a load)
-  load_item(wA, xA, 0, nitems > 0);
-  load_item(wB, xB, 1, nitems > 1);
-  {
-    const int ff = tid & 255;
-    resid0 = a.h_io[(int64_t)(ff >> 4) * a.ldh + (int)blockIdx.x * 16 + (ff & 15)];
-  }
-  for (int j = 0; j < nitems; j += 3) {
-    load_item(wC, xC, j + 2, j + 2 < nitems);
-    __builtin_amdgcn_sched_barrier(0);
-    process(wA, xA, j);
-    if (j + 1 >= nitems) break;
-    __builtin_amdgcn_sched_barrier(0);
-    load_item(wA, xA, j + 3, j + 3 < nitems);
-    __builtin_amdgcn_sched_barrier(0);
-    process(wB, xB, j + 1);
-    if (j + 2 >= nitems) break;
-    __builtin_amdgcn_sched_barrier(0);
-    load_item(wB, xB, j + 4, j + 4 < nitems);
-    __builtin_amdgcn_sched_barrier(0);
-    process(wC, xC, j + 2);
-  }
-}
-
-// Measured (scripts/ab_prof.sh, same box, in the cycle): down_proj 22.98 us against 20.50 us for the 16-wave form —
-// twice the bytes in flight per CU, half the waves: slower, like every other deeper queue tried in rounds 2 and 3.
-#ifndef DFL_CHUNK8  // A/B switch: 1 = the K-chunked residual GEMM runs as k_gemm_chunk8 (8 waves, three buffers)
-#define DFL_CHUNK8 0
-#endif
 
 // the instantiation for this launch's row sources (a normalised source needs the NORM kernels)
 template <int MT, bool CHUNKED, int EPI>
 void launch_gemm(const GemmArgs &a, dim3 grid, hipStream_t stream) {
   bool norm = false;
   for (int mt = 0; mt < MT; ++mt) norm |= a.src[mt].mode == 2;
-  if (norm && !CHUNKED)   // fp32-partial launches may cut K over grid.y: the producer's partial sums; all others: own sums
-    hipLaunchKernelGGL((k_gemm<MT, CHUNKED, EPI, CHUNKED ? 0 : ((EPI == EPI_F32 || !DFL_NORM_OWN) ? 2 : 1)>), grid, dim3(1024), 0, stream, a);
-  else
-    hipLaunchKernelGGL((k_gemm<MT, CHUNKED, EPI, 0>), grid, dim3(1024), 0, stream, a);
+  if constexpr (!CHUNKED) {  // (the chunked form takes no normalised source: its callers reject one)
+    if (norm) {
+      hipLaunchKernelGGL((k_gemm<MT, false, EPI, true>), grid, dim3(1024), 0, stream, a);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((k_gemm<MT, CHUNKED, EPI, false>), grid, dim3(1024), 0, stream, a);
 }
 
 // Cross-workgroup finish of the fused argmax: one wave per row.  margin_out (optional):
@@ -954,11 +796,8 @@ extern "C" int dfl_gemm_resid(const void *wp, const dfl_rows *x, int N, int K, v
   } else {  // walk K in chunks of 16 waves x 4 steps inside the workgroup
     DFL_REQUIRE(a.src[0].mode != 2, "dfl_gemm_resid: a normalised source needs K <= 4096");
     a.nfr = 4;
-    a.nch = (KS + 63) / 64;  // 64 k-steps per chunk in both forms: 16 waves x 4, or 8 waves x 8
-    if (DFL_CHUNK8)
-      hipLaunchKernelGGL((k_gemm_chunk8<0>), grid, dim3(512), 0, (hipStream_t)stream, a);
-    else
-      launch_gemm<1, true, EPI_RESID>(a, grid, (hipStream_t)stream);
+    a.nch = (KS + 63) / 64;  // 64 k-steps per chunk: 16 waves x 4
+    launch_gemm<1, true, EPI_RESID>(a, grid, (hipStream_t)stream);
   }
   DFL_CHECK_LAUNCH("dfl_gemm_resid");
   return DFL_OK;

@@ -10,7 +10,8 @@
 // back with conflict-free ds_read_b128: no transpose, no swizzle, no register staging.  The target keeps ONE copy of its
 // weights for prefill and verify (NativeTarget(keep_hf = False)).
 //
-// k_pgemm: 256 threads = 4 waves (2 x 2), block tile 128 columns x 128 rows, 64-deep K steps, two LDS stages (64 KiB),
+// k_pgemm: 256 threads = 4 waves (2 x 2), block tile 128 columns x 128 rows, 64-deep K steps, two LDS stages (64 KiB;
+// three of 24 KiB for the 64-row blocks),
 // each wave 4 x 4 MFMA tiles (64 accumulator VGPRs); the 8 row blocks of a column block share blockIdx % 8, i.e. an XCD
 // and its L2, so the weights leave HBM once.  Epilogues: bf16 rows / residual add (+ tap copy) / SiLU(gate) * up -> frag16.
 #include "gemm_rows.h"
@@ -37,10 +38,14 @@ typedef const __attribute__((address_space(1))) void glb_void;
 // MW = row tiles per wave: 4 -> block tile 128 columns x 128 rows; 2 -> 128 x 64 (twice the workgroups: the N = 4096
 // projections o_proj / down_proj have only 32 column blocks, and ONE 4-wave workgroup per CU leaves the matrix pipe idle
 // whenever it waits for its own LDS-DMA: 115 -> see DESIGN.md for the measured step)
-template <int EPI, int MW>
+// NST = LDS stages: NST - 1 in flight while one is in the MFMAs (two workgroups per CU up to 80 KiB each).
+template <int EPI, int MW, int NST>
 __global__ __launch_bounds__(256) void k_pgemm(PGemmArgs a) {
   constexpr int MB = 2 * MW;  // row tiles per block
-  __shared__ bf16x8 lds[2][16 + 2 * MB][64];  // [stage][slot: 0..15 = W (n tile, k-step), 16.. = X (m tile, k-step)][lane]
+  constexpr int PER = (16 + 2 * MB) / 4;  // LDS-DMA instructions per wave and stage
+  static_assert(PER == 8 || PER == 6, "vmcnt immediates below");
+  static_assert(NST == 2 || NST == 3, "stage counts measured");
+  __shared__ bf16x8 lds[NST][16 + 2 * MB][64];  // [stage][slot: 0..15 = W (n tile, k-step), 16.. = X (m tile, k-step)][lane]
   const int tid = threadIdx.x;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l = tid & 63;
@@ -80,12 +85,25 @@ __global__ __launch_bounds__(256) void k_pgemm(PGemmArgs a) {
 #pragma unroll
     for (int j = 0; j < MW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  stage(0, 0);
+#pragma unroll
+  for (int i = 0; i < NST - 1; ++i)
+    if (i < KT) stage(i, i);
+  int buf = 0;
   for (int kt = 0; kt < KT; ++kt) {
-    const int buf = kt & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of stage kt has landed in LDS
-    __syncthreads();  // ... and everyone's; every wave has finished reading buffer buf ^ 1 (iteration kt - 1)
-    if (kt + 1 < KT) stage(kt + 1, buf ^ 1);
+    // this wave's share of stage kt has landed in LDS (vmcnt is in order: min(NST - 2, KT - 1 - kt) later stages may
+    // still be in flight)
+    const int later = KT - 1 - kt;
+    if (NST >= 3 && later >= 1) {
+      if (PER == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    // ... and everyone's; every wave has finished reading the buffer of iteration kt - 1 (its MFMAs have consumed the
+    // ds_reads).  A bare s_barrier: __syncthreads() carries a fence, i.e. vmcnt(0) — the stages in flight.
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + NST - 1 < KT) stage(kt + NST - 1, buf == 0 ? NST - 1 : buf - 1);  // into the buffer of iteration kt - 1
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 af[4], bq[MW];
@@ -98,6 +116,7 @@ __global__ __launch_bounds__(256) void k_pgemm(PGemmArgs a) {
 #pragma unroll
         for (int j = 0; j < MW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bq[j], acc[i][j], 0, 0, 0);
     }
+    buf = buf == NST - 1 ? 0 : buf + 1;
   }
 
   // D layout (A = W rows n, B = x^T columns m): lane L, register r = column 4 (L >> 4) + r of the n tile, row L & 15
@@ -428,10 +447,14 @@ bool pgemm_fill(PGemmArgs &a, const void *wp, const void *xf, int P, int N, int 
 template <int EPI>
 void pgemm_launch(const PGemmArgs &a, hipStream_t st) {
   // 128-row blocks unless that leaves fewer than two workgroups per CU
+  // LDS stages, measured at P = 1024 on the 8B shapes (scripts/bench_prefill.py, whole prefill, same box):
+  // 128-row blocks 2 / 3 / 4 stages (64 / 96 / 128 KiB): 20.9 / 22.5 / 22.5 ms — two workgroups per CU beat a deeper
+  // queue; 64-row blocks 2 / 3 / 4 stages (48 / 72 / 96 KiB): 21.4 / 20.9 / 22.6 ms.  The wave tile (64 x 64) reads
+  // 16 KiB of LDS per 32 MFMAs, i.e. the whole LDS bandwidth at the MFMA peak: the kernel is LDS-bound, not latency-bound.
   if ((a.ntiles / 8) * (a.mtiles / 8) >= 512)
-    hipLaunchKernelGGL((k_pgemm<EPI, 4>), dim3((a.ntiles / 8) * (a.mtiles / 8)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_pgemm<EPI, 4, 2>), dim3((a.ntiles / 8) * (a.mtiles / 8)), dim3(256), 0, st, a);
   else
-    hipLaunchKernelGGL((k_pgemm<EPI, 2>), dim3((a.ntiles / 8) * (a.mtiles / 4)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_pgemm<EPI, 2, 3>), dim3((a.ntiles / 8) * (a.mtiles / 4)), dim3(256), 0, st, a);
 }
 
 }  // namespace

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turn a pmc_summary.py CSV into profiles/<round>_pmc_kernels.json: the HBM bytes per launch of the kernels bench.py's
-`roofline` object names (gate/up GEMM + SiLU epilogue = k_gemm<1, false, 1, 2>, the largest share of the cycle; lm_head GEMM
-+ fused argmax = k_gemm<1, false, 2, 2>), stamped with the hash of the sources the kernels are built from so that bench.py
+`roofline` object names (gate/up GEMM + SiLU epilogue = k_gemm<1, false, 1, true>, the largest share of the cycle; lm_head GEMM
++ fused argmax = k_gemm<1, false, 2, true>), stamped with the hash of the sources the kernels are built from so that bench.py
 can refuse the numbers once a kernel has changed.
 usage: pmc_kernels_json.py <summary.csv> <out.json>"""
 import csv, hashlib, json, os, sys
@@ -9,7 +9,7 @@ import csv, hashlib, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNEL_SOURCES = ["dflash_amd/csrc/gemm_skinny.hip", "dflash_amd/csrc/gemm_rows.h", "dflash_amd/csrc/dfl_common.h"]
 # (round 3 names: k_gemm<MT, CHUNKED, EPI, NORM>; the normalised-source instantiations are the ones the cycle runs)
-KERNELS = {"gate_up": ("k_gemm<1,false,1,2>", 2 * 12288 * 4096 * 2), "lm_head": ("k_gemm<1,false,2,2>", 151936 * 4096 * 2)}
+KERNELS = {"gate_up": ("k_gemm<1,false,1,true>", 2 * 12288 * 4096 * 2), "lm_head": ("k_gemm<1,false,2,true>", 151936 * 4096 * 2)}
 
 
 def source_hash():
