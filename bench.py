@@ -235,7 +235,7 @@ def gpu_leg(args, rank, world, dev):
     # PMC passes cannot run inside the timed bench (rocprofv3 --pmc serialises and slows the run): `traffic` is the
     # committed per-launch HBM byte count of these very kernels — accepted only while the hash of the kernels' sources
     # stored beside it still matches (scripts/pmc_kernels_json.py); a changed kernel reports null until re-profiled
-    traffic, traffic_note = {}, "no PMC summary for the current kernel sources"
+    traffic, rp_us, traffic_note = {}, {}, "no PMC summary for the current kernel sources"
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     try:
         from pmc_kernels_json import source_hash
@@ -244,17 +244,24 @@ def gpu_leg(args, rank, world, dev):
                 rec = json.load(open(os.path.join(ROOT, "profiles", fn)))
                 if rec.get("kernel_source_sha256_16") == source_hash():
                     traffic = {k: v.get("hbm_bytes_per_launch") for k, v in rec.get("kernels", {}).items()}
+                    rp_us = {k: v.get("rocprof_avg_us") for k, v in rec.get("kernels", {}).items()}
                     traffic_note = f"profiles/{fn} (kernel sources unchanged since)"
                     break
     except Exception as e:   # never let bookkeeping break the measurement
         traffic_note = f"PMC summary not read: {type(e).__name__}"
     GATE_UP_BYTES = 2 * 12288 * 4096 * 2   # Qwen3-8B: gate and up, [12288][4096] bf16 each
     ev_note = ("achieved/avg_ms from HIP events recorded on the launch stream right before and right after the GEMM launch, "
-               "every timed cycle; traffic = 2*FETCH_SIZE+WRITE_SIZE bytes per launch: " + traffic_note)
+               "every timed cycle (an event pair also spans the dependent launch boundary, ~2-3 us: rocprof_avg_ms is the "
+               "kernel's own duration in the committed rocprofv3 --kernel-trace --stats run of this command, same kernel "
+               "sources); traffic = 2*FETCH_SIZE+WRITE_SIZE bytes per launch: " + traffic_note)
+
+    def rp(key, nbytes):   # the committed profile's figure for the same kernel, while the sources are unchanged
+        us = rp_us.get(key)
+        return {"rocprof_avg_ms": us / 1e3, "frac_rocprof": nbytes / (us * 1e-6) / 8e12} if us else {}
     lm_entry = {"kernel": "k_gemm<1,false,EPI_ARGMAX> (lm_head GEMM + fused argmax; 2 launches per cycle)", "bound": "hbm",
                 "achieved": LM_HEAD_BYTES / (lm_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                 "frac": LM_HEAD_BYTES / (lm_ms * 1e-3) / 1e9 / 8000.0, "traffic": traffic.get("lm_head"),
-                "bytes_per_launch": LM_HEAD_BYTES, "avg_ms": lm_ms, "note": ev_note}
+                "bytes_per_launch": LM_HEAD_BYTES, "avg_ms": lm_ms, **rp("lm_head", LM_HEAD_BYTES), "note": ev_note}
     if gu_ms:
         # the roofline object names the kernel with the largest share of the timed cycle: the gate/up GEMM
         # with the fused SiLU*up epilogue, one launch per layer of target and draft; the lm_head GEMM rides beside it
@@ -262,7 +269,8 @@ def gpu_leg(args, rank, world, dev):
                               "share of the cycle)", "bound": "hbm",
                     "achieved": GATE_UP_BYTES / (gu_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                     "frac": GATE_UP_BYTES / (gu_ms * 1e-3) / 1e9 / 8000.0, "traffic": traffic.get("gate_up"),
-                    "bytes_per_launch": GATE_UP_BYTES, "avg_ms": gu_ms, "note": ev_note, "also": [lm_entry]}
+                    "bytes_per_launch": GATE_UP_BYTES, "avg_ms": gu_ms, **rp("gate_up", GATE_UP_BYTES), "note": ev_note,
+                    "also": [lm_entry]}
     else:
         roofline = lm_entry
     kv_bytes = 20480 * (P + 16)

@@ -3,7 +3,8 @@
 `roofline` object names (gate/up GEMM + SiLU epilogue = k_gemm<1, false, 1, true>, the largest share of the cycle; lm_head GEMM
 + fused argmax = k_gemm<1, false, 2, true>), stamped with the hash of the sources the kernels are built from so that bench.py
 can refuse the numbers once a kernel has changed.
-usage: pmc_kernels_json.py <summary.csv> <out.json>"""
+usage: pmc_kernels_json.py <summary.csv> <out.json> [<kernel_stats.csv of the rocprofv3 --kernel-trace --stats run>]
+(the third argument adds each kernel's average duration by rocprofv3, which bench.py prints beside its own HIP-event figure)"""
 import csv, hashlib, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -36,5 +37,13 @@ if __name__ == "__main__":
                                "hbm_bytes_per_launch": int(r["hbm_bytes_corrected"]), "algorithmic_bytes": alg,
                                "traffic_over_algorithmic": int(r["hbm_bytes_corrected"]) / alg,
                                "dispatches": int(r["dispatches"])}
+    if len(sys.argv) > 3:   # rocprofv3 --stats: "Name","Calls","TotalDurationNs","AverageNs",...
+        out["kernel_stats_source"] = os.path.relpath(sys.argv[3], ROOT)
+        for r in csv.DictReader(open(sys.argv[3])):
+            nm = r["Name"].replace(" ", "")
+            for key, (kname, _) in KERNELS.items():
+                if "::" + kname + "(" in nm and key in out["kernels"]:
+                    out["kernels"][key]["rocprof_avg_us"] = float(r["AverageNs"]) / 1e3
+                    out["kernels"][key]["rocprof_calls"] = int(r["Calls"])
     json.dump(out, open(sys.argv[2], "w"), indent=1)
     print(json.dumps(out))
