@@ -131,6 +131,7 @@ class DecodeSession:
         self.hook_calls = 0
         self.stopped = False
         self.events = None  # set to a dict to have cycle() record (start, end) event pairs per phase
+        self.record_events = True  # False: record nothing new, but still hand a run-ahead draft's pairs to self.events
         self.draft_logits = None  # set to a bf16 [32, V] buffer to have the draft's logits materialised into it
         # the tapped rows live here from a verify to the next draft (own buffer: several
         # sessions may be interleaved on one NativeTarget)
@@ -153,7 +154,7 @@ class DecodeSession:
             self.target_hidden = _taps(out.hidden_states, self.model.target_layer_ids)
 
     def _mark(self, key, which):
-        if self.events is not None:
+        if self.events is not None and self.record_events:
             e = torch.cuda.Event(enable_timing=True)
             e.record()
             self.events.setdefault(key, [None, None])[which] = e
@@ -164,7 +165,7 @@ class DecodeSession:
         = the record's tau), block = what the accept kernel re-armed.  Upper bounds for the host-side checks only."""
         m = self.model
         ev = None
-        if self.events is not None:   # the caller times the phases: this draft's event pairs belong to the NEXT cycle
+        if self.events is not None and self.record_events:   # the caller times the phases: this draft's pairs belong to the NEXT cycle
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             ev[0].record()
         hid = m.draft_block(self.dcache, th_rows=self.taps_buf[:16], tau=16, bs=bs, pos0=self.start + self.max_bs,
