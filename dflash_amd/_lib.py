@@ -81,6 +81,13 @@ SIGNATURES = {
     "dfl_prefill_norm_pack": (_i, [_p, _i64, _i, _i, _p, _f, _p, _p]),
     "dfl_prefill_qk_rope": (_i, [_p, _i64, _i, _i, _i, _i, _i, _i, _p, _p, _f, _p, _p, _i, _i, _p, _p, _i, _i, _p]),
     "dfl_prefill_attn": (_i, [_p, _i64, _i, _p, _p, _i, _i, _i, _i, _f, _p, _p]),
+    "dfl_prefill_moe_max_tiles": (_i64, [_i, _i, _i]),
+    "dfl_prefill_moe_max_items": (_i64, [_i, _i, _i]),
+    "dfl_prefill_moe_route": (_i, [_p, _i64, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
+    "dfl_prefill_moe_gather": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p]),
+    "dfl_prefill_moe_gemm_silu": (_i, [_p, _i64, _p, _p, _p, _i, _i, _i, _p, _i, _p]),
+    "dfl_prefill_moe_gemm_down": (_i, [_p, _i64, _p, _p, _p, _i, _i, _i, _p, _p, _i, _p]),
+    "dfl_prefill_moe_combine": (_i, [_p, _p, _i, _i, _i, _p, _i64, _p, _i64, _p]),
     # ---- ragged batch of requests
     "dfl_batch_tiles": (_i, [_i]),
     "dfl_batch_ksplit": (_i, [_i]),

@@ -11,10 +11,9 @@
 // row in bf16 (index_add_ in expert order); here the sum over experts stays in fp32 and is rounded once, where the
 // dense MLP's Linear output is rounded — fewer roundings than the reference, inside the stated bf16 tolerance.
 #include "gemm_rows.h"
+#include "moe_route.h"
 
 namespace {
-
-__device__ __forceinline__ bool route_better(float v, int i, float ov, int oi) { return v > ov || (v == ov && i < oi); }
 
 // one wavefront per row (16 rows), E <= 256
 __global__ __launch_bounds__(1024) void k_moe_route(const bf16_t *logits, int ld, int E, int top_k, int norm_topk,
@@ -24,61 +23,14 @@ __global__ __launch_bounds__(1024) void k_moe_route(const bf16_t *logits, int ld
   const int nv = dyn ? dyn[dyn_word] : 16;
   for (int e = tid; e < E; e += 1024) active[e] = 0;
   __syncthreads();
-  float p[4];
-  float mx = -INFINITY;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int e = l + 64 * j;
-    p[j] = e < E ? bf2f(logits[(int64_t)m * ld + e]) : -INFINITY;
-    mx = fmaxf(mx, p[j]);
-  }
-  mx = wave_max(mx);
-  float sum = 0.f;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    p[j] = (l + 64 * j) < E ? __expf(p[j] - mx) : 0.f;
-    sum += p[j];
-  }
-  sum = wave_sum(sum);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    p[j] = p[j] / sum;  // softmax(dtype = float), Qwen3MoeTopKRouter.forward
     const int e = l + 64 * j;
     if (e < E) wt[(int64_t)m * E + e] = (bf16_t)0.f;
   }
-  // top-k: k rounds of a wave argmax, (probability desc, expert index asc)
-  float sel_v[8];
+  float sel_v[8], tot;
   int sel_i[8];
-  float tot = 0.f;
-#pragma unroll
-  for (int r = 0; r < 8; ++r) {   // unrolled with a guard: a runtime index would send sel_v / sel_i to scratch memory
-    if (r >= top_k) break;
-    float bv = -1.f;
-    int bi = 0x7fffffff;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int e = l + 64 * j;
-      if (e < E && route_better(p[j], e, bv, bi)) {
-        bv = p[j];
-        bi = e;
-      }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(bv, o, 64);
-      const int oi = __shfl_xor(bi, o, 64);
-      if (route_better(ov, oi, bv, bi)) {
-        bv = ov;
-        bi = oi;
-      }
-    }
-    sel_v[r] = bv;
-    sel_i[r] = bi;
-    tot += bv;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (l + 64 * j == bi) p[j] = -1.f;  // taken
-  }
+  route_row(logits + (int64_t)m * ld, E, top_k, l, sel_v, sel_i, tot);
   if (m < nv && l == 0) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) {

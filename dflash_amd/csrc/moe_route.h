@@ -1,0 +1,64 @@
+// Routing arithmetic of Qwen3MoeTopKRouter.forward (tf:models/qwen3_moe/modeling_qwen3_moe.py): softmax over the gate
+// Linear's bf16 logits in fp32, top-k by (probability descending, expert index ascending), optional renormalisation.
+// One wavefront per row, E <= 256 (lane l owns experts l, l + 64, l + 128, l + 192).  Shared by the decode-side kernel
+// (moe.hip: k_moe_route, the <= 16 rows of a verify block) and the prefill-side one (prefill.hip: k_pmoe_route).
+#pragma once
+#include "dfl_common.h"
+
+__device__ __forceinline__ bool route_better(float v, int i, float ov, int oi) { return v > ov || (v == ov && i < oi); }
+
+// logits_row: the row's E bf16 logits.  On return every lane holds the k selected experts (sel_i, in selection order),
+// their softmax probabilities (sel_v) and the sum of those (tot).
+__device__ __forceinline__ void route_row(const bf16_t *logits_row, int E, int top_k, int l, float (&sel_v)[8],
+                                          int (&sel_i)[8], float &tot) {
+  float p[4];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = l + 64 * j;
+    p[j] = e < E ? bf2f(logits_row[e]) : -INFINITY;
+    mx = fmaxf(mx, p[j]);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    p[j] = (l + 64 * j) < E ? __expf(p[j] - mx) : 0.f;
+    sum += p[j];
+  }
+  sum = wave_sum(sum);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) p[j] = p[j] / sum;  // softmax(dtype = float)
+  tot = 0.f;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {   // unrolled with a guard: a runtime index would send sel_v / sel_i to scratch memory
+    sel_v[r] = 0.f;
+    sel_i[r] = 0;
+    if (r >= top_k) continue;
+    float bv = -1.f;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = l + 64 * j;
+      if (e < E && route_better(p[j], e, bv, bi)) {
+        bv = p[j];
+        bi = e;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (route_better(ov, oi, bv, bi)) {
+        bv = ov;
+        bi = oi;
+      }
+    }
+    sel_v[r] = bv;
+    sel_i[r] = bi;
+    tot += bv;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (l + 64 * j == bi) p[j] = -1.f;  // taken
+  }
+}

@@ -15,10 +15,11 @@
 // each wave 4 x 4 MFMA tiles (64 accumulator VGPRs); the 8 row blocks of a column block share blockIdx % 8, i.e. an XCD
 // and its L2, so the weights leave HBM once.  Epilogues: bf16 rows / residual add (+ tap copy) / SiLU(gate) * up -> frag16.
 #include "gemm_rows.h"
+#include "moe_route.h"
 
 namespace {
 
-enum { PEPI_ROWS = 0, PEPI_RESID = 1, PEPI_SILU = 2 };
+enum { PEPI_ROWS = 0, PEPI_RESID = 1, PEPI_SILU = 2, PEPI_SCALE32 = 3 };
 
 struct PGemmArgs {
   const bf16x8 *wp;  // [ntiles][KS][64]
@@ -30,6 +31,13 @@ struct PGemmArgs {
   int64_t ldtap;
   bf16x8 *act;       // SILU: frag16 row tiles of I columns [mtiles][KSo][64]
   int KSo;
+  // grouped form (the experts of a sparse-MoE layer, rows gathered per expert into 16-row tiles): the workgroup's
+  // row block comes from a device-built work list of (expert, first gathered tile, tiles <= 4) items
+  const int32_t *items, *n_items;
+  int64_t w_expert_stride;  // bf16x8 units between the experts' packed weights
+  float *out32;             // SCALE32: out32[gathered row][n] = routing weight of the row x sum (fp32, no rounding)
+  const float *row_w;       // [gathered row]
+  int64_t ld32;
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -39,7 +47,8 @@ typedef const __attribute__((address_space(1))) void glb_void;
 // projections o_proj / down_proj have only 32 column blocks, and ONE 4-wave workgroup per CU leaves the matrix pipe idle
 // whenever it waits for its own LDS-DMA: 115 -> see DESIGN.md for the measured step)
 // NST = LDS stages: NST - 1 in flight while one is in the MFMAs (two workgroups per CU up to 80 KiB each).
-template <int EPI, int MW, int NST>
+// GRP: the grouped form (64-row blocks): blockIdx.x = item * column blocks + column block.
+template <int EPI, int MW, int NST, bool GRP = false>
 __global__ __launch_bounds__(256) void k_pgemm(PGemmArgs a) {
   constexpr int MB = 2 * MW;  // row tiles per block
   constexpr int PER = (16 + 2 * MB) / 4;  // LDS-DMA instructions per wave and stage
@@ -51,8 +60,16 @@ __global__ __launch_bounds__(256) void k_pgemm(PGemmArgs a) {
   const int l = tid & 63;
   const int nbx = a.ntiles >> 3, nby = a.mtiles / MB;
   // column block / row block of this workgroup: the nby row blocks of a column block are 8 apart in blockIdx
-  int nb, mb;
-  {
+  int nb, mb = 0, tile0 = 0, ntl = MB;
+  const bf16x8 *wbase = a.wp;
+  if (GRP) {
+    const int item = blockIdx.x / nbx;
+    nb = blockIdx.x - item * nbx;
+    if (item >= *a.n_items) return;  // (uniform: the grid is sized for the worst case)
+    wbase += (int64_t)a.items[3 * item] * a.w_expert_stride;
+    tile0 = a.items[3 * item + 1];
+    ntl = a.items[3 * item + 2];
+  } else {
     const int b = blockIdx.x, per = 8 * nby, g = b / per;
     if (g < (nbx >> 3)) {
       const int rem = b - g * per;
@@ -63,7 +80,10 @@ __global__ __launch_bounds__(256) void k_pgemm(PGemmArgs a) {
       nb = (nbx >> 3) * 8 + rem % tail;
       mb = rem / tail;
     }
+    tile0 = mb * MB;
   }
+  // (row tile j of the block: tile0 + j; a grouped item with fewer than MB tiles reads its last tile again)
+  auto tile_of = [&](int j) { return tile0 + (GRP && j >= ntl ? ntl - 1 : j); };
   const int wn = w & 1, wm = w >> 1;  // the wave's 64 columns x 64 rows inside the block tile
   const int KT = a.KS >> 1;           // 64-deep steps
 
@@ -73,8 +93,8 @@ __global__ __launch_bounds__(256) void k_pgemm(PGemmArgs a) {
     for (int i = 0; i < (16 + 2 * MB) / 4; ++i) {
       const int slot = i * 4 + w;  // wave-uniform
       const int s16 = slot < 16 ? slot : slot - 16;  // fragment of its operand: (tile s16 >> 1, k-step s16 & 1)
-      const bf16x8 *src = (slot < 16 ? a.wp + ((size_t)(nb * 8 + (s16 >> 1)) * a.KS + kt * 2 + (s16 & 1)) * 64
-                                     : a.xf + ((size_t)(mb * MB + (s16 >> 1)) * a.KS + kt * 2 + (s16 & 1)) * 64) + l;
+      const bf16x8 *src = (slot < 16 ? wbase + ((size_t)(nb * 8 + (s16 >> 1)) * a.KS + kt * 2 + (s16 & 1)) * 64
+                                     : a.xf + ((size_t)tile_of(s16 >> 1) * a.KS + kt * 2 + (s16 & 1)) * 64) + l;
       __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)&lds[buf][slot][0], 16, 0, 0);
     }
   };
@@ -123,7 +143,8 @@ __global__ __launch_bounds__(256) void k_pgemm(PGemmArgs a) {
   const int fm = l & 15, fg = l >> 4;
 #pragma unroll
   for (int j = 0; j < MW; ++j) {
-    const int mt = mb * MB + wm * MW + j;
+    if (GRP && wm * MW + j >= ntl) continue;
+    const int mt = tile0 + wm * MW + j;
     const int m = mt * 16 + fm;
     if (EPI == PEPI_SILU) {
 #pragma unroll
@@ -139,6 +160,16 @@ __global__ __launch_bounds__(256) void k_pgemm(PGemmArgs a) {
         }
         bf16_t *dst = reinterpret_cast<bf16_t *>(a.act + ((size_t)mt * a.KSo + (n0 >> 5)) * 64 + ((n0 >> 3) & 3) * 16 + fm) + (n0 & 7);
         *reinterpret_cast<bf16x4 *>(dst) = o;
+      }
+    } else if (EPI == PEPI_SCALE32) {  // an expert's down projection: scaled by the row's routing weight, kept fp32
+      const float rw = a.row_w[m];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int n0 = (nb * 8 + wn * 4 + i) * 16 + 4 * fg;
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = rw * acc[i][j][r];
+        *reinterpret_cast<f32x4 *>(a.out32 + (int64_t)m * a.ld32 + n0) = o;
       }
     } else {
 #pragma unroll
@@ -279,6 +310,7 @@ struct PAttnArgs {
   float scale_log2;
   bf16x8 *out_frag;
   int KSo;  // n_q * 128 / 32
+  int hq;   // query heads per workgroup (1, 2 or 4, all of one kv head): its waves = hq heads x 4 / hq query tiles
 };
 
 typedef __attribute__((address_space(3))) bf16x4 plds_bf16x4;
@@ -305,9 +337,11 @@ __global__ __launch_bounds__(256) void k_pattn(PAttnArgs a) {
   const int tid = threadIdx.x;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l = tid & 63, qi = l & 15, g = l >> 4;
-  const int head = blockIdx.y;
+  // The hq heads of a workgroup share a kv head and a query tile: their waves walk the SAME K / V tiles at the same
+  // pace, so that tile leaves L2 once per workgroup and is an L1 hit for the other waves.
+  const int head = blockIdx.y * a.hq + w % a.hq;
   const int nqt = (a.P + 15) >> 4;
-  const int t = nqt - 1 - ((int)blockIdx.x * 4 + w);  // wave-uniform; late (long) tiles first
+  const int t = nqt - 1 - ((int)blockIdx.x * (4 / a.hq) + w / a.hq);  // wave-uniform; late (long) tiles first
   if (t < 0) return;                                  // the whole wave leaves: no barrier in this kernel
   const bf16_t *K = a.kc + (int64_t)(head / a.G) * a.cache_rows * 128;
   const bf16_t *V = a.vc + (int64_t)(head / a.G) * a.cache_rows * 128;
@@ -426,6 +460,174 @@ __global__ __launch_bounds__(256) void k_pattn(PAttnArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Sparse-MoE MLP over the P prompt rows (Qwen3MoeSparseMoeBlock, tf:models/qwen3_moe/modeling_qwen3_moe.py; the
+// reference runs it inside the HF forward of model/dflash.py:218-225, a Python loop over the experts).  The (row, slot)
+// pairs of a layer are sorted by expert on the device and each expert's rows gathered into 16-row frag16 tiles, so
+// that every expert's weights are read ONCE by MFMA row blocks of its own rows (the grouped form of k_pgemm):
+//   k_pmoe_route    one wave per row: fp32 softmax / top-k / renormalise (moe_route.h) -> (expert, weight) per slot
+//   k_pmoe_plan     one workgroup: counts and ranks per expert, tile offsets, the work list (expert, first tile,
+//                   tiles <= 4) of the grouped GEMMs, source row and routing weight of every gathered row
+//   k_pmoe_gather   one workgroup per gathered tile: the source rows' normalised fragments (zero for padding rows)
+//   k_pgemm<SILU, grouped>, k_pgemm<SCALE32, grouped>: act = silu(x Wg_e^T) * (x Wu_e^T); out32 = w * (act Wd_e^T)
+//   k_pmoe_combine  one wave per row: the k slot rows summed in fp32 (slot order), rounded once, residual add (+ tap) —
+//                   the rounding points of the decode-side kernels (moe.hip), fewer than HF's per-expert bf16 adds.
+__global__ __launch_bounds__(256) void k_pmoe_route(const bf16_t *logits, int64_t ld, int P, int E, int top_k, int norm_topk,
+                                                    int32_t *pair_e, float *pair_w) {
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
+  if (m >= P) return;
+  float sel_v[8], tot;
+  int sel_i[8];
+  route_row(logits + m * ld, E, top_k, l, sel_v, sel_i, tot);
+  if (l == 0) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+      if (r < top_k) {
+        const float w = norm_topk ? sel_v[r] / tot : sel_v[r];
+        pair_e[m * 8 + r] = sel_i[r];
+        pair_w[m * 8 + r] = rbf(w);  // the routing weights are cast to the hidden dtype (Qwen3MoeTopKRouter.forward)
+      }
+  }
+}
+
+// ONE workgroup: per-expert counts and each pair's rank among its expert's rows (LDS atomics: the order inside an
+// expert's tiles is arbitrary, the arithmetic of a row does not depend on it), tile offsets (prefix over the experts),
+// the work list of the grouped GEMMs, and for every gathered row its source row and routing weight (-1 / 0: padding).
+__global__ __launch_bounds__(1024) void k_pmoe_plan(const int32_t *pair_e, const float *pair_w, int P, int E, int top_k,
+                                                    int32_t *cnt_out, int32_t *tile_off, int32_t *items, int32_t *n_items,
+                                                    int32_t *posmap, int32_t *src_row, float *row_w, int max_rows, int tpi) {
+  __shared__ int cnt[256], toff[256], ioff[256];
+  const int tid = threadIdx.x;
+  if (tid < 256) cnt[tid] = 0;
+  for (int i = tid; i < max_rows; i += 1024) {
+    src_row[i] = -1;
+    row_w[i] = 0.f;
+  }
+  __syncthreads();
+  const int npair = P * top_k;
+  // (ranks are kept in posmap until the offsets are known)
+  for (int i = tid; i < npair; i += 1024) {
+    const int m = i / top_k, r = i - m * top_k;
+    posmap[m * 8 + r] = atomicAdd(&cnt[pair_e[m * 8 + r]], 1);
+  }
+  __syncthreads();
+  if (tid < 64) {  // one wave: exclusive prefix of tiles and of work items over the experts, 4 experts per lane
+    int nt[4], ni[4], st = 0, si = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = tid * 4 + j;
+      nt[j] = e < E ? (cnt[e] + 15) >> 4 : 0;
+      ni[j] = (nt[j] + tpi - 1) / tpi;
+      st += nt[j];
+      si += ni[j];
+    }
+    int pt = st, pi = si;  // inclusive scan over the lanes
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int ot = __shfl_up(pt, o, 64), oi = __shfl_up(pi, o, 64);
+      if (tid >= o) {
+        pt += ot;
+        pi += oi;
+      }
+    }
+    int bt = pt - st, bi = pi - si;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = tid * 4 + j;
+      if (e < 256) {
+        toff[e] = bt;
+        ioff[e] = bi;
+      }
+      bt += nt[j];
+      bi += ni[j];
+    }
+    if (tid == 63) {
+      n_items[0] = pi;
+      n_items[1] = pt;
+    }
+  }
+  __syncthreads();
+  if (tid < E) {
+    cnt_out[tid] = cnt[tid];
+    tile_off[tid] = toff[tid];
+    const int nt = (cnt[tid] + 15) >> 4;
+    for (int b = 0, w = ioff[tid]; b < nt; b += tpi, ++w) {
+      items[3 * w] = tid;
+      items[3 * w + 1] = toff[tid] + b;
+      items[3 * w + 2] = nt - b < tpi ? nt - b : tpi;
+    }
+  }
+  for (int i = tid; i < npair; i += 1024) {
+    const int m = i / top_k, r = i - m * top_k;
+    const int pos = toff[pair_e[m * 8 + r]] * 16 + posmap[m * 8 + r];
+    posmap[m * 8 + r] = pos;
+    src_row[pos] = m;
+    row_w[pos] = pair_w[m * 8 + r];
+  }
+}
+
+// one workgroup per gathered tile: chunk c (8 values) of its 16 rows is one contiguous 256-byte run of the tile
+__global__ __launch_bounds__(256) void k_pmoe_gather(const bf16x8 *xf, int KS, const int32_t *src_row, const int32_t *n_items,
+                                                     bf16x8 *xg) {
+  const int t = blockIdx.x;
+  if (t >= n_items[1]) return;
+  const int r = threadIdx.x & 15;
+  const int m = src_row[t * 16 + r];
+  const bf16x8 *src = xf + (size_t)((m < 0 ? 0 : m) >> 4) * KS * 64 + ((m < 0 ? 0 : m) & 15);
+  bf16x8 *dst = xg + (size_t)t * KS * 64 + r;
+  const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int c = threadIdx.x >> 4; c < KS * 4; c += 16) dst[c * 16] = m < 0 ? z : src[c * 16];
+}
+
+// one workgroup per row, its four waves a quarter of the columns each
+__global__ __launch_bounds__(256) void k_pmoe_combine(const float *out32, int64_t ld32, const int32_t *posmap, int P, int H,
+                                                      int top_k, bf16_t *h, int64_t ldh, bf16_t *tap, int64_t ldtap) {
+  const int m = blockIdx.x;
+  int pos[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) pos[r] = r < top_k ? posmap[m * 8 + r] : 0;
+  for (int c = threadIdx.x; c < H / 4; c += 256) {
+    f32x4 v[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+      v[r] = r < top_k ? *reinterpret_cast<const f32x4 *>(out32 + (int64_t)pos[r] * ld32 + c * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16_t *hp = h + (int64_t)m * ldh + c * 4;
+    const bf16x4 hv = *reinterpret_cast<const bf16x4 *>(hp);
+    bf16x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) s += v[r][j];  // slot order (the padding slots of top_k < 8 add zero)
+      o[j] = f2bf(rbf(bf2f(hv[j]) + rbf(s)));
+    }
+    *reinterpret_cast<bf16x4 *>(hp) = o;
+    if (tap) *reinterpret_cast<bf16x4 *>(tap + (int64_t)m * ldtap + c * 4) = o;
+  }
+}
+
+bool pmoe_gemm_fill(PGemmArgs &a, const void *wp, int64_t w_expert_stride, const void *xg, const int32_t *items,
+                    const int32_t *n_items, int max_items, int N, int K, const char *who) {
+  if (!wp || !xg || !items || !n_items) {
+    dfl_set_error("%s: null pointer", who);
+    return false;
+  }
+  if (max_items < 1 || N <= 0 || K <= 0 || N % 128 || K % 64 || w_expert_stride != (int64_t)N * K) {
+    dfl_set_error("%s: need N%%128==0, K%%64==0, expert stride = N*K (N=%d K=%d)", who, N, K);
+    return false;
+  }
+  a.wp = (const bf16x8 *)wp;
+  a.xf = (const bf16x8 *)xg;
+  a.KS = K / 32;
+  a.ntiles = N / 16;
+  a.mtiles = 4;
+  a.P = 0;
+  a.items = items;
+  a.n_items = n_items;
+  a.w_expert_stride = w_expert_stride / 8;
+  return true;
+}
+
 bool pgemm_fill(PGemmArgs &a, const void *wp, const void *xf, int P, int N, int K, const char *who) {
   if (!wp || !xf) {
     dfl_set_error("%s: null pointer", who);
@@ -531,10 +733,99 @@ extern "C" int dfl_prefill_attn(const void *q_rows, int64_t ldq, int q_col, cons
   DFL_REQUIRE(q_rows && kcache && vcache && out_frag, "dfl_prefill_attn: null pointer");
   DFL_REQUIRE(P >= 1 && P <= cache_rows && n_q >= 1 && n_kv >= 1 && n_q % n_kv == 0 && ldq % 8 == 0 && q_col % 8 == 0,
               "dfl_prefill_attn: bad shape (P=%d cache_rows=%d n_q=%d n_kv=%d)", P, cache_rows, n_q, n_kv);
-  PAttnArgs a{(const bf16_t *)q_rows, ldq, q_col, (const bf16_t *)kcache, (const bf16_t *)vcache, cache_rows, P, n_q / n_kv,
-              scale * 1.4426950408889634f, (bf16x8 *)out_frag, n_q * 4};
-  const int nqt = (P + 15) / 16;
-  hipLaunchKernelGGL(k_pattn, dim3((nqt + 3) / 4, n_q), dim3(256), 0, (hipStream_t)stream, a);
+  const int G = n_q / n_kv;
+  int hq = G % 4 == 0 ? 4 : (G % 2 == 0 ? 2 : 1);
+  // (measured, 8B shapes, whole prefill: P = 1024 20.85 ms either way; P = 4096, 12 layers: 33.0 -> 28.3 ms)
+  PAttnArgs a{(const bf16_t *)q_rows, ldq, q_col, (const bf16_t *)kcache, (const bf16_t *)vcache, cache_rows, P, G,
+              scale * 1.4426950408889634f, (bf16x8 *)out_frag, n_q * 4, hq};
+  const int nqt = (P + 15) / 16, per = 4 / hq;
+  hipLaunchKernelGGL(k_pattn, dim3((nqt + per - 1) / per, n_q / hq), dim3(256), 0, (hipStream_t)stream, a);
   DFL_CHECK_LAUNCH("dfl_prefill_attn");
+  return DFL_OK;
+}
+
+// ---- sparse-MoE MLP of the prefill (see k_pmoe_route above).  Scratch, all caller-owned: pair_e / posmap
+// int32 [P][8], pair_w float [P][8], cnt / tile_off int32 [E], items int32 [3 * max_items], n_items int32 [2]
+// (items, tiles), src_row int32 / row_w float [max_tiles * 16], xg bf16 [max_tiles * 16 * H],
+// with max_items = dfl_prefill_moe_max_items(P, top_k, E) and max_tiles = dfl_prefill_moe_max_tiles(P, top_k, E).
+extern "C" int64_t dfl_prefill_moe_max_tiles(int P, int top_k, int E) { return ((int64_t)P * top_k + 15) / 16 + E; }
+extern "C" int64_t dfl_prefill_moe_max_items(int P, int top_k, int E) { return ((int64_t)P * top_k + 63) / 64 + E; }
+// rows_per_item: 64 or 128 rows (4 or 8 gathered tiles) per work item of the grouped GEMMs, the same value for the
+// route call and both GEMMs of a layer.  128 reads an expert's weights once where it serves 65..128 rows (30B-A3B widths,
+// P = 1024, ~64 rows per expert: 566 -> 539 us per layer); 64 wastes less on experts with few rows.
+
+extern "C" int dfl_prefill_moe_route(const void *logits, int64_t ld, int P, int E, int top_k, int norm_topk, int32_t *pair_e,
+                                     float *pair_w, int32_t *cnt, int32_t *tile_off, int32_t *items, int32_t *n_items,
+                                     int32_t *posmap, int32_t *src_row, float *row_w, int rows_per_item, void *stream) {
+  DFL_REQUIRE(rows_per_item == 64 || rows_per_item == 128, "dfl_prefill_moe_route: rows_per_item must be 64 or 128");
+  DFL_REQUIRE(logits && pair_e && pair_w && cnt && tile_off && items && n_items && posmap && src_row && row_w,
+              "dfl_prefill_moe_route: null pointer");
+  DFL_REQUIRE(P >= 1 && E >= 1 && E <= 256 && top_k >= 1 && top_k <= 8 && top_k <= E && ld >= E,
+              "dfl_prefill_moe_route: need 1 <= top_k <= 8, top_k <= E <= 256, ld >= E (E=%d top_k=%d)", E, top_k);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_pmoe_route, dim3((P + 3) / 4), dim3(256), 0, st, (const bf16_t *)logits, ld, P, E, top_k, norm_topk,
+                     pair_e, pair_w);
+  hipLaunchKernelGGL(k_pmoe_plan, dim3(1), dim3(1024), 0, st, pair_e, pair_w, P, E, top_k, cnt, tile_off, items, n_items, posmap,
+                     src_row, row_w, (int)dfl_prefill_moe_max_tiles(P, top_k, E) * 16, rows_per_item / 16);
+  DFL_CHECK_LAUNCH("dfl_prefill_moe_route");
+  return DFL_OK;
+}
+
+extern "C" int dfl_prefill_moe_gather(const void *x_frag, int P, int H, int top_k, int E, const int32_t *src_row,
+                                      const int32_t *n_items, void *xg, void *stream) {
+  DFL_REQUIRE(x_frag && src_row && n_items && xg, "dfl_prefill_moe_gather: null pointer");
+  DFL_REQUIRE(P >= 1 && H > 0 && H % 32 == 0 && top_k >= 1 && top_k <= 8 && E >= 1, "dfl_prefill_moe_gather: bad shape");
+  hipLaunchKernelGGL(k_pmoe_gather, dim3((int)dfl_prefill_moe_max_tiles(P, top_k, E)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16x8 *)x_frag, H / 32, src_row, n_items, (bf16x8 *)xg);
+  DFL_CHECK_LAUNCH("dfl_prefill_moe_gather");
+  return DFL_OK;
+}
+
+extern "C" int dfl_prefill_moe_gemm_silu(const void *wp_gateup_e, int64_t w_expert_stride, const void *xg, const int32_t *items,
+                                         const int32_t *n_items, int max_items, int I, int K, void *act_g, int rows_per_item,
+                                         void *stream) {
+  PGemmArgs a{};
+  DFL_REQUIRE(rows_per_item == 64 || rows_per_item == 128, "dfl_prefill_moe_gemm_silu: rows_per_item must be 64 or 128");
+  DFL_REQUIRE(act_g && I > 0 && I % 64 == 0, "dfl_prefill_moe_gemm_silu: need I%%64==0");
+  if (!pmoe_gemm_fill(a, wp_gateup_e, w_expert_stride, xg, items, n_items, max_items, 2 * I, K, "dfl_prefill_moe_gemm_silu"))
+    return DFL_EINVAL;
+  a.act = (bf16x8 *)act_g;
+  a.KSo = I / 32;
+  if (rows_per_item == 128)
+    hipLaunchKernelGGL((k_pgemm<PEPI_SILU, 4, 2, true>), dim3(max_items * (a.ntiles / 8)), dim3(256), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL((k_pgemm<PEPI_SILU, 2, 3, true>), dim3(max_items * (a.ntiles / 8)), dim3(256), 0, (hipStream_t)stream, a);
+  DFL_CHECK_LAUNCH("dfl_prefill_moe_gemm_silu");
+  return DFL_OK;
+}
+
+extern "C" int dfl_prefill_moe_gemm_down(const void *wp_down_e, int64_t w_expert_stride, const void *act_g, const int32_t *items,
+                                         const int32_t *n_items, int max_items, int H, int I, const float *row_w, float *out32,
+                                         int rows_per_item, void *stream) {
+  PGemmArgs a{};
+  DFL_REQUIRE(rows_per_item == 64 || rows_per_item == 128, "dfl_prefill_moe_gemm_down: rows_per_item must be 64 or 128");
+  DFL_REQUIRE(row_w && out32, "dfl_prefill_moe_gemm_down: null pointer");
+  if (!pmoe_gemm_fill(a, wp_down_e, w_expert_stride, act_g, items, n_items, max_items, H, I, "dfl_prefill_moe_gemm_down"))
+    return DFL_EINVAL;
+  a.row_w = row_w;
+  a.out32 = out32;
+  a.ld32 = H;
+  if (rows_per_item == 128)
+    hipLaunchKernelGGL((k_pgemm<PEPI_SCALE32, 4, 2, true>), dim3(max_items * (a.ntiles / 8)), dim3(256), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL((k_pgemm<PEPI_SCALE32, 2, 3, true>), dim3(max_items * (a.ntiles / 8)), dim3(256), 0, (hipStream_t)stream, a);
+  DFL_CHECK_LAUNCH("dfl_prefill_moe_gemm_down");
+  return DFL_OK;
+}
+
+extern "C" int dfl_prefill_moe_combine(const float *out32, const int32_t *posmap, int P, int H, int top_k, void *h_io,
+                                       int64_t ldh, void *tap, int64_t ldtap, void *stream) {
+  DFL_REQUIRE(out32 && posmap && h_io, "dfl_prefill_moe_combine: null pointer");
+  DFL_REQUIRE(P >= 1 && H > 0 && H % 4 == 0 && top_k >= 1 && top_k <= 8 && ldh >= H && ldh % 4 == 0 &&
+                  (!tap || (ldtap >= H && ldtap % 4 == 0)),
+              "dfl_prefill_moe_combine: bad shape");
+  hipLaunchKernelGGL(k_pmoe_combine, dim3(P), dim3(256), 0, (hipStream_t)stream, out32, (int64_t)H, posmap, P, H, top_k,
+                     (bf16_t *)h_io, ldh, (bf16_t *)tap, ldtap);
+  DFL_CHECK_LAUNCH("dfl_prefill_moe_combine");
   return DFL_OK;
 }

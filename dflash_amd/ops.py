@@ -685,3 +685,54 @@ def prefill_attn(qkv: torch.Tensor, P: int, q_col: int, kcache, vcache, n_q: int
     check(lib().dfl_prefill_attn(qkv.data_ptr(), qkv.stride(0), q_col, _p(kcache, BF16, "kcache"), _p(vcache, BF16, "vcache"),
                                  kcache.shape[1], P, n_q, n_kv, scale, _p(out_frag, BF16, "out_frag"), _stream()),
           "dfl_prefill_attn")
+
+
+# ---- sparse-MoE MLP of the prefill (csrc/prefill.hip: k_pmoe_*, the grouped k_pgemm) ----------------------------
+def prefill_moe_scratch(P: int, H: int, I: int, E: int, top_k: int, router_cols: int, device) -> dict:
+    """Caller-owned scratch of dfl_prefill_moe_* for P prompt rows (sizes in include/dflash_hip.h)."""
+    L = lib()
+    mt, mi = int(L.dfl_prefill_moe_max_tiles(P, top_k, E)), int(L.dfl_prefill_moe_max_items(P, top_k, E))
+    zi = lambda *s: torch.zeros(*s, dtype=I32, device=device)    # noqa: E731
+    zf = lambda *s: torch.zeros(*s, dtype=F32, device=device)    # noqa: E731
+    # (128-row work items where an expert serves ~48 rows or more on average, see include/dflash_hip.h)
+    return dict(P=P, H=H, I=I, E=E, top_k=top_k, max_tiles=mt, max_items=mi, rows_per_item=128 if P * top_k >= 48 * E else 64,
+                rlog=torch.zeros(prefill_rows_padded(P), router_cols, dtype=BF16, device=device),
+                pair_e=zi(P, 8), posmap=zi(P, 8), pair_w=zf(P, 8), cnt=zi(E), tile_off=zi(E), src_row=zi(mt * 16),
+                items=zi(3 * mi), n_items=zi(2), xg=torch.zeros(mt * 16 * H, dtype=BF16, device=device),
+                act_g=torch.zeros(mt * 16 * I, dtype=BF16, device=device), row_w=zf(mt * 16), out32=zf(mt * 16, H))
+
+
+def prefill_moe_route(rlog: torch.Tensor, P: int, sc: dict, norm_topk: bool = True) -> None:
+    """Routing of the P rows from their router logits (bf16 rows) + the plan of the grouped GEMMs, into the scratch."""
+    check(lib().dfl_prefill_moe_route(rlog.data_ptr(), rlog.stride(0), P, sc["E"], sc["top_k"], int(bool(norm_topk)),
+                                      sc["pair_e"].data_ptr(), sc["pair_w"].data_ptr(), sc["cnt"].data_ptr(),
+                                      sc["tile_off"].data_ptr(), sc["items"].data_ptr(), sc["n_items"].data_ptr(),
+                                      sc["posmap"].data_ptr(), sc["src_row"].data_ptr(), sc["row_w"].data_ptr(),
+                                      sc["rows_per_item"], _stream()),
+          "dfl_prefill_moe_route")
+
+
+def prefill_moe_mlp(router_wp, gu_e, down_e, x_frag, P: int, H: int, I: int, E: int, top_k: int, norm_topk: bool,
+                    h_io: torch.Tensor, sc: dict, tap=None) -> None:
+    """Qwen3MoeSparseMoeBlock over the P prompt rows of one layer (tf:models/qwen3_moe/modeling_qwen3_moe.py):
+    x_frag = the ln2-normalised rows as frag16 tiles; h_io <- h_io + MLP(x) (+ tap copy).  router_wp: the gate Linear's
+    weight packed with its rows padded to a multiple of 128; gu_e / down_e: [E, ...] packed expert weights."""
+    assert sc["P"] >= P and sc["H"] == H and sc["I"] == I and sc["E"] == E and sc["top_k"] == top_k
+    assert gu_e.shape[0] == E and down_e.shape[0] == E and h_io.dtype == BF16 and h_io.stride(1) == 1
+    L, st = lib(), _stream()
+    rlog = sc["rlog"]
+    prefill_gemm_rows(router_wp, x_frag, P, rlog.shape[1], H, rlog)
+    prefill_moe_route(rlog, P, sc, norm_topk)
+    check(L.dfl_prefill_moe_gather(_p(x_frag, BF16, "x_frag"), P, H, top_k, E, sc["src_row"].data_ptr(), sc["n_items"].data_ptr(),
+                                   sc["xg"].data_ptr(), st), "dfl_prefill_moe_gather")
+    check(L.dfl_prefill_moe_gemm_silu(_p(gu_e, BF16, "gu_e"), gu_e.stride(0), sc["xg"].data_ptr(), sc["items"].data_ptr(),
+                                      sc["n_items"].data_ptr(), sc["max_items"], I, H, sc["act_g"].data_ptr(),
+                                      sc["rows_per_item"], st),
+          "dfl_prefill_moe_gemm_silu")
+    check(L.dfl_prefill_moe_gemm_down(_p(down_e, BF16, "down_e"), down_e.stride(0), sc["act_g"].data_ptr(),
+                                      sc["items"].data_ptr(), sc["n_items"].data_ptr(), sc["max_items"], H, I,
+                                      sc["row_w"].data_ptr(), sc["out32"].data_ptr(), sc["rows_per_item"], st),
+          "dfl_prefill_moe_gemm_down")
+    tp, ldt = (None, 0) if tap is None else (_p(tap, BF16, "tap") if tap.is_contiguous() else tap.data_ptr(), tap.stride(0))
+    check(L.dfl_prefill_moe_combine(sc["out32"].data_ptr(), sc["posmap"].data_ptr(), P, H, top_k, h_io.data_ptr(),
+                                    h_io.stride(0), tp, ldt, st), "dfl_prefill_moe_combine")

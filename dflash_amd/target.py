@@ -169,6 +169,13 @@ class NativeTarget:
                 rw = torch.zeros(ep, self.H, dtype=BF16, device=dev)
                 rw[:self.E] = w(p + "mlp.gate.weight")
                 lw["router"] = ops.pack_weight(rw)
+                if ep % 128:    # the prefill's router GEMM (prefill.hip:k_pgemm) takes column blocks of 128
+                    rp = torch.zeros((self.E + 127) // 128 * 128, self.H, dtype=BF16, device=dev)
+                    rp[:self.E] = rw[:self.E]
+                    lw["router_p"] = ops.pack_weight(rp)
+                    del rp
+                else:
+                    lw["router_p"] = lw["router"]
                 del gup, dwn, rw
             else:
                 lw["gu"] = ops.pack_weight_gateup(w(p + "mlp.gate_proj.weight"), w(p + "mlp.up_proj.weight"))
@@ -218,14 +225,15 @@ class NativeTarget:
             self.src["xn"] = [ops.rows_frag(ws["xn"][t]) for t in range(NT)]
             self.src["xn1"] = [ops.rows_frag(ws["xn1"][t]) for t in range(NT)]
         q_dim, kv_dim = self.n_q * 128, self.n_kv * 128
-        self._pf = None
-        self.native_prefill = (prefill == "native" and not self.is_moe and (q_dim + 2 * kv_dim) % 128 == 0
-                               and self.H % 128 == 0 and self.I % 64 == 0 and q_dim % 64 == 0)
+        self._pf = self._pf_moe = None
+        dense_ok = all("gu_e" in lw for lw in self.layers) or self.I % 64 == 0   # (a dense MLP layer needs I % 64)
+        self.native_prefill = (prefill == "native" and (q_dim + 2 * kv_dim) % 128 == 0 and self.H % 128 == 0 and dense_ok
+                               and q_dim % 64 == 0 and (not self.is_moe or self.Ie % 64 == 0))
         self.prefill_attn = "native"   # "sdpa": the causal attention core of the prefill through torch (round-3 first form)
         self._rotary = getattr(hf_model.model, "rotary_emb", None)
         if not keep_hf:
             if not self.native_prefill:
-                raise NotImplementedError("NativeTarget(keep_hf=False) needs the native prefill (dense target, widths % 128)")
+                raise NotImplementedError("NativeTarget(keep_hf=False) needs the native prefill (widths % 128, FFN widths % 64)")
             if self.lm_wp is None:
                 self.lm_wp = ops.pack_weight(self.lm_head.weight.detach().to(BF16).contiguous())
             self.hf = None
@@ -292,7 +300,8 @@ class NativeTarget:
         q_dim, kv_dim, nqkv = self.q_dim, self.kv_dim, self.nqkv
         if self._pf is None or self._pf["h"].shape[0] < Pp:
             z = lambda *s: torch.zeros(*s, dtype=BF16, device=dev)  # noqa: E731
-            self._pf = dict(h=z(Pp, H), xf=z(Pp * max(H, q_dim)), qkv=z(Pp, nqkv), act=z(Pp * I), attn=z(Pp, q_dim),
+            dense_I = I if any("gu" in lw for lw in self.layers) else 0
+            self._pf = dict(h=z(Pp, H), xf=z(Pp * max(H, q_dim)), qkv=z(Pp, nqkv), act=z(Pp * max(dense_I, 1)), attn=z(Pp, q_dim),
                             logits=z(16, self.V), ids=torch.zeros(16, dtype=torch.int64, device=dev))
         pf = self._pf
         h, xf, qkv, act, attn = pf["h"], pf["xf"], pf["qkv"], pf["act"], pf["attn"]
@@ -322,11 +331,20 @@ class NativeTarget:
                 ops.prefill_norm_pack(attn, P, q_dim, None, self.eps, xf)      # rows -> frag16 tiles, no norm
             ops.prefill_gemm_resid(lw["o"], xf, P, H, q_dim, h)
             ops.prefill_norm_pack(h, P, H, lw["ln2"], self.eps, xf)
-            ops.prefill_gemm_silu(lw["gu"], xf, P, I, H, act)
             tap = None
             if want and (i + 1) in want and i + 1 < self.L:   # (the last layer's output only exists final-normed in HF)
                 tap = torch.empty(P, H, dtype=BF16, device=dev)
                 kept[i + 1] = tap.unsqueeze(0)
+            if "gu_e" in lw:   # sparse-MoE layer: rows sorted by expert, grouped MFMA GEMMs over each expert's rows
+                if self._pf_moe is None or self._pf_moe["P"] < P:
+                    self._pf_moe = ops.prefill_moe_scratch(P, H, self.Ie, self.E, self.top_k,
+                                                           (self.E + 127) // 128 * 128, dev)
+                ops.prefill_moe_mlp(lw["router_p"], lw["gu_e"], lw["down_e"], xf, P, H, self.Ie, self.E, self.top_k,
+                                    self.norm_topk, h, self._pf_moe, tap=tap)
+                if self.debug_routing is not None:    # tests: the experts every prompt row was routed to
+                    self.debug_routing.append((i, self._pf_moe["pair_e"][:P, :self.top_k].clone()))
+                continue
+            ops.prefill_gemm_silu(lw["gu"], xf, P, I, H, act)
             ops.prefill_gemm_resid(lw["down"], act, P, H, I, h, tap=tap)
         # last prompt row: final norm + lm_head on its 16-row tile (the decode path's GEMM, norm applied in its prologue)
         if self.lm_wp is None:
@@ -343,7 +361,7 @@ class NativeTarget:
         return SimpleNamespace(logits=logits, hidden_states=_HiddenStates(kept, self.L + 1) if output_hidden_states else None)
 
     def _prefill_hf(self, input_ids, cache, output_hidden_states):
-        """Through the wrapped model, K/V copied into the preallocated cache (MoE targets, odd widths, prefill="hf")."""
+        """Through the wrapped model, K/V copied into the preallocated cache (odd widths, prefill="hf")."""
         from transformers import DynamicCache
         P = input_ids.shape[1]
         tmp = DynamicCache()

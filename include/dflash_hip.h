@@ -387,6 +387,42 @@ int dfl_prefill_qk_rope(void *qkv_rows, int64_t ld, int P, int q_col, int k_col,
 int dfl_prefill_attn(const void *q_rows, int64_t ldq, int q_col, const void *kcache, const void *vcache, int cache_rows,
                      int P, int n_q, int n_kv, float scale, void *out_frag, void *stream);
 
+/* Sparse-MoE MLP of the prefill: Qwen3MoeSparseMoeBlock over the P prompt rows of one layer of an MoE target
+ * (tf:models/qwen3_moe/modeling_qwen3_moe.py: Qwen3MoeTopKRouter.forward + Qwen3MoeExperts.forward; the reference
+ * reaches it through the HF forward of model/dflash.py:218-225, a Python loop over the experts).  The layer's
+ * (row, slot) pairs are sorted by expert on the device and each expert's rows gathered into 16-row frag16 tiles, so
+ * every expert's packed weights are read once by MFMA row blocks of its own rows.  Call order per layer:
+ *   router logits = dfl_prefill_gemm_rows(router weight padded to a multiple of 128 rows) on the ln2-normalised tiles
+ *   dfl_prefill_moe_route   fp32 softmax / top-k (probability desc, index asc) / renormalise per row -> pair_e / pair_w
+ *                           [P][8]; then (one workgroup) per-expert counts cnt and tile offsets, the work list items =
+ *                           (expert, first gathered tile, tiles <= 4) with n_items[0] = items, [1] = tiles, posmap
+ *                           [P][8] = gathered row of each pair, src_row / row_w [gathered row] = its source row (-1:
+ *                           padding) and routing weight (bf16 value, as float)
+ *   dfl_prefill_moe_gather  the source rows' normalised fragments into the gathered tiles xg (zero for padding rows)
+ *   dfl_prefill_moe_gemm_silu   act_g = silu(xg Wg_e^T) * (xg Wu_e^T) per expert (gate/up interleaved as dfl_pack_weight_gateup)
+ *   dfl_prefill_moe_gemm_down   out32[gathered row][H] = row_w * (act_g Wd_e^T), fp32
+ *   dfl_prefill_moe_combine     h[m] = bf16(h[m] + bf16(sum over the row's k slots of out32)) (+ tap copy): the sum over
+ *                               experts is rounded once (HF: per-expert bf16 adds), as in dfl_moe_down's consumer.
+ * Scratch is caller-owned: cnt / tile_off int32 [E], items int32 [3 * max_items], src_row int32 / row_w float
+ * [max_tiles * 16], xg bf16 [max_tiles * 16 * H], act_g bf16 [max_tiles * 16 * I], out32 float [max_tiles * 16 * H].
+ * rows_per_item: 64 or 128 rows of one expert per work item (4 or 8 gathered tiles), the same in the three calls of a
+ * layer that take it; 128 reads an expert's weights once where it serves up to 128 rows.  E <= 256, top_k <= 8, H % 128 == 0, I % 64 == 0, expert strides = elements per expert. */
+int64_t dfl_prefill_moe_max_tiles(int P, int top_k, int E);
+int64_t dfl_prefill_moe_max_items(int P, int top_k, int E);
+int dfl_prefill_moe_route(const void *logits, int64_t ld, int P, int E, int top_k, int norm_topk, int32_t *pair_e,
+                          float *pair_w, int32_t *cnt, int32_t *tile_off, int32_t *items, int32_t *n_items, int32_t *posmap,
+                          int32_t *src_row, float *row_w, int rows_per_item, void *stream);
+int dfl_prefill_moe_gather(const void *x_frag, int P, int H, int top_k, int E, const int32_t *src_row, const int32_t *n_items,
+                           void *xg, void *stream);
+int dfl_prefill_moe_gemm_silu(const void *wp_gateup_e, int64_t w_expert_stride, const void *xg, const int32_t *items,
+                              const int32_t *n_items, int max_items, int I, int K, void *act_g, int rows_per_item,
+                              void *stream);
+int dfl_prefill_moe_gemm_down(const void *wp_down_e, int64_t w_expert_stride, const void *act_g, const int32_t *items,
+                              const int32_t *n_items, int max_items, int H, int I, const float *row_w, float *out32,
+                              int rows_per_item, void *stream);
+int dfl_prefill_moe_combine(const float *out32, const int32_t *posmap, int P, int H, int top_k, void *h_io, int64_t ldh,
+                            void *tap, int64_t ldtap, void *stream);
+
 /* ======================================================================================
  * Ragged batch of requests on one GPU (BASELINE.json configs[2]; SURVEY.md §8e: "within a
  * GPU the requests are a ragged batch for the kernels: shared weight stream, per-request

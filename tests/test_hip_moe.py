@@ -212,7 +212,7 @@ def _moe_verify_vs_hf(hf, mlp_only, tap_layers, kv_layers, min_same, fp32_arbite
     from dflash_amd import NativeTarget
     cfg = hf.config
     L, E, top_k, Hd, V = cfg.num_hidden_layers, cfg.num_experts, cfg.num_experts_per_tok, cfg.hidden_size, cfg.vocab_size
-    nt = NativeTarget(hf)
+    nt = NativeTarget(hf, prefill="hf")    # (the verify is the subject here; the native MoE prefill has its own tests below)
     assert nt.is_moe and all(("gu" in nt.layers[i]) == (i in mlp_only) for i in range(L))
     g = torch.Generator().manual_seed(7)
     P, bs = 50, 16
@@ -370,3 +370,193 @@ def test_moe_target_in_the_ragged_batch():
     for i, (a, b) in enumerate(zip(singles, outs)):
         assert b.output_ids[0].tolist() == a.output_ids[0].tolist() == Gs[i][:lens[i] + n_new].tolist(), f"request {i}"
         assert b.acceptance_lengths == a.acceptance_lengths, f"request {i}"
+
+
+# ----------------------------------------------------------------------------- prefill of an MoE target on the kernels
+def _routed_alike(routing, router_logits, top_k, P):
+    """Rows whose top-k expert SETS agree with the HF forward's in every MoE layer (a near-tie at the k-th place may fall
+    either way between two bf16 evaluations of the same router)."""
+    same = torch.ones(P, dtype=torch.bool)
+    for (li, pe), rl in zip(routing, router_logits):
+        ref = torch.topk(torch.softmax(rl.float().view(P, -1), dim=-1), top_k, dim=-1).indices.sort(dim=-1).values.cpu()
+        same &= (pe.cpu().long().sort(dim=-1).values == ref).all(dim=-1)
+    return same
+
+
+def _moe_prefill_vs_hf(name, hf, P, taps, min_same, fp32_arbiter=False, seed=5):
+    from transformers import DynamicCache
+    from dflash_amd import NativeTarget
+    cfg = hf.config
+    L, top_k, V = cfg.num_hidden_layers, cfg.num_experts_per_tok, cfg.vocab_size
+    nt = NativeTarget(hf)
+    assert nt.is_moe and nt.native_prefill
+    g = torch.Generator().manual_seed(seed)
+    prompt = torch.randint(0, 2000, (1, P), generator=g).to(dev())
+    cache = nt.new_cache(P + 64)
+    nt.debug_routing = []
+    out = nt.prefill(prompt, cache, output_hidden_states=True, tap_layers=taps)
+    routing, nt.debug_routing = nt.debug_routing, None
+    rc = DynamicCache()
+    with torch.inference_mode():
+        ref = hf(prompt, position_ids=torch.arange(P, device=dev())[None], past_key_values=rc, use_cache=True,
+                 output_hidden_states=True, output_router_logits=True)
+    assert len(routing) == len(ref.router_logits) == sum("gu_e" in lw for lw in nt.layers)
+    same = _routed_alike(routing, ref.router_logits, top_k, P)
+    ref_last = ref.logits[0, -1:]
+    arb = None
+    if fp32_arbiter:
+        import copy
+        hf32 = copy.deepcopy(hf).float()
+        rc32 = DynamicCache()
+        with torch.inference_mode():
+            ref32 = hf32(prompt, position_ids=torch.arange(P, device=dev())[None], past_key_values=rc32, use_cache=True,
+                         output_router_logits=True)
+        same &= _routed_alike(routing, ref32.router_logits, top_k, P)
+        arb = (ref32.logits[0, -1:].float(), rc32)
+        del hf32
+    assert int(same.sum()) >= min_same, (int(same.sum()), P)
+    rows = same.nonzero()[:, 0].to(dev())
+    assert out.logits.shape == (1, 1, V) and cache.get_seq_length() == P
+
+    def closer(what, got, ref_bf16, ref_fp32):
+        """The HF forward adds the expert outputs one by one into a bf16 tensor, this path sums them in fp32 and rounds
+        once: two bf16 evaluations that differ by more than two roundings of the same arithmetic (most after the next
+        layer's per-head k-norm).  The fp32 forward arbitrates: the native result is at least as close to it as HF's."""
+        e_nat, e_hf = (got.float() - ref_fp32.float()).abs(), (ref_bf16.float() - ref_fp32.float()).abs()
+        scale = float(ref_fp32.abs().max())
+        print(f"[parity] {name} {what} vs fp32 forward: native max {float(e_nat.max()) / scale:.3e} mean "
+              f"{float(e_nat.mean()) / scale:.3e}; HF bf16 max {float(e_hf.max()) / scale:.3e} mean {float(e_hf.mean()) / scale:.3e}")
+        assert float(e_nat.mean()) <= 1.05 * float(e_hf.mean()) + 1e-6 * scale, what
+        assert float(e_nat.max()) <= 1.25 * float(e_hf.max()) + 1e-6 * scale, what
+
+    if arb is None:
+        if bool(same[P - 1]):
+            H.assert_close(f"{name} prefill logits (last row)", out.logits[0], ref_last)
+        for l in taps:
+            H.assert_close(f"{name} prefill tap layer {l}", out.hidden_states[l + 1][0][rows], ref.hidden_states[l + 1][0][rows])
+        for li in (0, L - 1):
+            H.assert_close(f"{name} prefill K layer {li}", cache.k[li][:, :P][:, rows], rc.layers[li].keys[0][:, rows],
+                           max_rel=H.KV_MAX_REL)
+            H.assert_close(f"{name} prefill V layer {li}", cache.v[li][:, :P][:, rows], rc.layers[li].values[0][:, rows],
+                           max_rel=H.KV_MAX_REL)
+    else:
+        r32, rc32 = arb
+        assert bool(same[P - 1]), "pick a seed whose last row routes alike"
+        closer("logits (last row)", out.logits[0], ref_last, r32)
+        H.assert_close(f"{name} prefill logits (last row)", out.logits[0], ref_last, max_rel=6e-2)
+        for li in (0, L - 1):
+            closer(f"K layer {li}", cache.k[li][:, :P][:, rows], rc.layers[li].keys[0][:, rows], rc32.layers[li].keys[0][:, rows])
+            closer(f"V layer {li}", cache.v[li][:, :P][:, rows], rc.layers[li].values[0][:, rows], rc32.layers[li].values[0][:, rows])
+            H.assert_close(f"{name} prefill V layer {li}", cache.v[li][:, :P][:, rows], rc.layers[li].values[0][:, rows],
+                           max_rel=6e-2)
+        for l in taps:
+            H.assert_close(f"{name} prefill tap layer {l}", out.hidden_states[l + 1][0][rows], ref.hidden_states[l + 1][0][rows],
+                           max_rel=6e-2)
+    return nt, prompt, cache, same
+
+
+@pytest.mark.parametrize("P,mlp_only", [(45, ()), (300, ()), (130, (1,))])
+def test_native_moe_prefill_matches_hf_forward(P, mlp_only):
+    """Prompt rows of a Qwen3MoeForCausalLM (16 experts, top-4; optionally a dense layer in between) through the native
+    prefill (rows sorted by expert, grouped MFMA GEMMs) vs the HF forward: last-row logits, taps, K/V on the rows that
+    both route alike (model/dflash.py:218-225 on an MoE target)."""
+    _moe_prefill_vs_hf(f"MoE P={P}", _moe_hf(mlp_only=mlp_only), P, taps=[0, 2], min_same=int(0.85 * P))
+
+
+def test_native_moe_prefill_at_30b_a3b_widths():
+    """Two layers of Qwen3-Coder-30B-A3B's widths (H 2048, 32 q / 4 kv heads, 128 experts of 768, top-8), 256 prompt rows."""
+    _moe_prefill_vs_hf("30B-A3B widths", _moe_hf(layers=2, E=128, top_k=8, Ie=768, hidden=2048, heads=32, kv=4, seed=43), 256,
+                       taps=[0], min_same=160, fp32_arbiter=True)
+
+
+@pytest.mark.parametrize("rows_per_item,P,skew", [(64, 70, False), (128, 70, False), (64, 300, True), (128, 300, True)])
+def test_moe_prefill_pieces_are_exact_on_integers(rows_per_item, P, skew):
+    """dfl_prefill_moe_*: with small-integer weights and activations every product and sum is exact, so the grouped
+    GEMMs, the gather and the combine must reproduce a torch evaluation of the same routed sum bit for bit."""
+    from dflash_amd import ops
+    g = torch.Generator().manual_seed(3)
+    Hd, Ie, E, k = 128, 64, 5, 2     # skew: expert 0 serves every row (19 tiles: several work items of one expert)
+    x = torch.randint(-2, 3, (P, Hd), generator=g).float()
+    gate = torch.randint(-1, 2, (E, Ie, Hd), generator=g).float()
+    up = torch.randint(-1, 2, (E, Ie, Hd), generator=g).float()
+    down = torch.randint(-1, 2, (E, Hd, Ie), generator=g).float()
+    logits = _tie_free_logits(P, E, g)
+    if skew:
+        logits[:, 0] = 20.0
+    h0 = torch.randint(-3, 4, (P, Hd), generator=g).float()
+    d = dev()
+    Pp = ops.prefill_rows_padded(P)
+    xr = torch.zeros(Pp, Hd, dtype=BF16, device=d)
+    xr[:P] = x.to(BF16)
+    xf = torch.zeros(Pp * Hd, dtype=BF16, device=d)
+    ops.prefill_norm_pack(xr, P, Hd, None, 1e-6, xf)
+    gu_e = torch.stack([ops.pack_weight_gateup(gate[e].to(BF16).to(d), up[e].to(BF16).to(d)) for e in range(E)])
+    down_e = torch.stack([ops.pack_weight(down[e].to(BF16).to(d)) for e in range(E)])
+    sc = ops.prefill_moe_scratch(P, Hd, Ie, E, k, 128, d)
+    sc["rows_per_item"] = rows_per_item
+    tpi = rows_per_item // 16
+    # the router GEMM is skipped: the logits are given (rows of the scratch buffer), the rest of the chain as in the product
+    L, st = ops.lib(), 0
+    sc["rlog"][:P, :E] = logits.to(d)
+    ops.prefill_moe_route(sc["rlog"], P, sc, True)
+    prob = torch.softmax(logits.float(), dim=-1)
+    tv, ti = torch.topk(prob, k, dim=-1)
+    wref = (tv / tv.sum(-1, keepdim=True)).to(BF16).float()
+    assert torch.equal(sc["pair_e"][:, :k].cpu().long(), ti)
+    assert torch.allclose(sc["pair_w"][:, :k].cpu(), wref, atol=8e-3)     # (division in fp32 here and there: a bf16 ulp)
+    cnt = torch.bincount(ti.flatten(), minlength=E)
+    assert torch.equal(sc["cnt"].cpu().long(), cnt)
+    n_items, n_tiles = sc["n_items"].tolist()
+    assert n_tiles == int(((cnt + 15) // 16).sum()) and n_items == int(((((cnt + 15) // 16) + tpi - 1) // tpi).sum())
+    h = torch.zeros(Pp, Hd, dtype=BF16, device=d)
+    h[:P] = h0.to(BF16)
+    # the remaining calls through the product wrapper would recompute the router GEMM: call the pieces
+    ops.check(L.dfl_prefill_moe_gather(xf.data_ptr(), P, Hd, k, E, sc["src_row"].data_ptr(), sc["n_items"].data_ptr(),
+                                       sc["xg"].data_ptr(), st), "gather")
+    ops.check(L.dfl_prefill_moe_gemm_silu(gu_e.data_ptr(), gu_e.stride(0), sc["xg"].data_ptr(), sc["items"].data_ptr(),
+                                          sc["n_items"].data_ptr(), sc["max_items"], Ie, Hd, sc["act_g"].data_ptr(), rows_per_item, st),
+              "silu")
+    ops.check(L.dfl_prefill_moe_gemm_down(down_e.data_ptr(), down_e.stride(0), sc["act_g"].data_ptr(), sc["items"].data_ptr(),
+                                          sc["n_items"].data_ptr(), sc["max_items"], Hd, Ie, sc["row_w"].data_ptr(),
+                                          sc["out32"].data_ptr(), rows_per_item, st), "down")
+    pw = sc["pair_w"][:, :k].cpu()
+    # every pair's gathered slot holds w * down_e(act_e(x)) of ITS row and expert, in fp32 (act in bf16 roundings as the kernel's)
+    pos = sc["posmap"][:, :k].cpu().long()
+    assert pos.flatten().unique().numel() == P * k
+    srow = sc["src_row"][:n_tiles * 16].cpu().long()
+    assert torch.equal(srow[pos.flatten()], torch.arange(P).repeat_interleave(k)) and int((srow >= 0).sum()) == P * k
+    out32 = sc["out32"].cpu()
+    total = torch.zeros(P, Hd)
+    for m in range(P):
+        for r in range(k):
+            e = int(ti[m, r])
+            gb, ub = (gate[e] @ x[m]).to(BF16).float(), (up[e] @ x[m]).to(BF16).float()
+            act = ((gb * torch.sigmoid(gb)).to(BF16).float() * ub).to(BF16).float()
+            want = pw[m, r] * (down[e] @ act)
+            got = out32[pos[m, r]]
+            assert torch.allclose(got, want, rtol=2e-2, atol=2e-2 * float(want.abs().max() + 1)), (m, r)   # (silu: __expf vs torch)
+            total[m] += got
+    ops.check(L.dfl_prefill_moe_combine(sc["out32"].data_ptr(), sc["posmap"].data_ptr(), P, Hd, k, h.data_ptr(), h.stride(0),
+                                        None, 0, st), "combine")
+    want_h = (h0.to(BF16).float() + total.to(BF16).float()).to(BF16)
+    assert torch.equal(h[:P].cpu(), want_h)
+    assert int(h[P:].abs().sum()) == 0
+
+
+def test_moe_target_one_copy_keep_hf_false():
+    """NativeTarget(keep_hf=False) on an MoE target: prefill + verify with the wrapped model gone give what the two-copy
+    target gives (same kernels, same weights)."""
+    from dflash_amd import NativeTarget
+    hf = _moe_hf()
+    a, b = NativeTarget(hf), NativeTarget(hf, keep_hf=False)
+    assert b.hf is None and b.native_prefill
+    g = torch.Generator().manual_seed(9)
+    P = 77
+    prompt = torch.randint(0, 2000, (1, P), generator=g).to(dev())
+    block = torch.randint(0, 2000, (16,), generator=g).to(dev())
+    ca, cb = a.new_cache(P + 64), b.new_cache(P + 64)
+    oa, ob = a.prefill(prompt, ca), b.prefill(prompt, cb)
+    assert torch.equal(oa.logits, ob.logits) and torch.equal(ca.k[:, :, :P], cb.k[:, :, :P])
+    pa, _ = a.verify(block, P, ca)
+    pb, _ = b.verify(block, P, cb)
+    assert torch.equal(pa, pb)
