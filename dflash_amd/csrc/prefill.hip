@@ -310,7 +310,7 @@ struct PAttnArgs {
   float scale_log2;
   bf16x8 *out_frag;
   int KSo;  // n_q * 128 / 32
-  int hq;   // query heads per workgroup (1, 2 or 4, all of one kv head): its waves = hq heads x 4 / hq query tiles
+  int hq;   // query heads per workgroup (1, 2 or 4, all of one kv head): its waves = hq heads x PA_NW / hq query tiles
 };
 
 typedef __attribute__((address_space(3))) bf16x4 plds_bf16x4;
@@ -332,70 +332,70 @@ __device__ __forceinline__ float pg_sum(float v) {
   return a + b;
 }
 
-__global__ __launch_bounds__(256) void k_pattn(PAttnArgs a) {
-  __shared__ __attribute__((aligned(16))) char lds[4 * 8192];
+// Causal attention of the prompt over itself, flash-style: a workgroup = 4 waves = hq query heads of ONE kv head x 4 / hq
+// 16-row query tiles, walking the 32-key tiles of that kv head together.  A tile (K 8 KB + V 8 KB) enters LDS once per
+// workgroup by LDS-DMA into a ring of PA_NS stages, three tiles in flight under the MFMAs of the current one (first form:
+// every wave fetched its own K / V tile into registers, one tile ahead — 2.5 us per tile and wave at P = 1024, the L2
+// latency).  The DMA writes a lane-linear image, so the bank swizzles are applied on the SOURCE side: lane j of a 1 KiB
+// request fetches the 16-byte chunk that belongs in slot j.  K rows: chunk c of key k sits at k * 256 + ((c ^ (k & 15)) << 4)
+// (conflict-free ds_read_b128 of the MFMA A fragments: lane (key qi, g) reads chunk 4 s + g); V rows: pv_swz (the layout
+// ds_read_b64_tr_b16 wants, csrc/attn_head.hip).  S^T = K Q^T, O^T += V^T P^T, base-2 online softmax, P in bf16.
+constexpr int PA_NS = 4, PA_NW = 8;  // ring stages; waves per workgroup (hq heads x PA_NW / hq query tiles)
+__global__ __launch_bounds__(64 * PA_NW) void k_pattn(PAttnArgs a) {
+  __shared__ __attribute__((aligned(1024))) char lds[PA_NS][2][8192];  // [stage][K | V]
   const int tid = threadIdx.x;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l = tid & 63, qi = l & 15, g = l >> 4;
-  // The hq heads of a workgroup share a kv head and a query tile: their waves walk the SAME K / V tiles at the same
-  // pace, so that tile leaves L2 once per workgroup and is an L1 hit for the other waves.
   const int head = blockIdx.y * a.hq + w % a.hq;
   const int nqt = (a.P + 15) >> 4;
-  const int t = nqt - 1 - ((int)blockIdx.x * (4 / a.hq) + w / a.hq);  // wave-uniform; late (long) tiles first
-  if (t < 0) return;                                  // the whole wave leaves: no barrier in this kernel
+  const int t_top = nqt - 1 - (int)blockIdx.x * (PA_NW / a.hq);  // the workgroup's longest query tile (late tiles first)
+  const int t = t_top - w / a.hq;                                // this wave's; < 0: no tile (it still feeds the ring)
   const bf16_t *K = a.kc + (int64_t)(head / a.G) * a.cache_rows * 128;
   const bf16_t *V = a.vc + (int64_t)(head / a.G) * a.cache_rows * 128;
-  char *my_v = lds + w * 8192;
-  const int qrow = t * 16 + qi, qrow_c = qrow < a.P ? qrow : a.P - 1;
+  const int qrow = t * 16 + qi, qrow_c = qrow < 0 ? 0 : (qrow < a.P ? qrow : a.P - 1);
   bf16x8 qf[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s)
     qf[s] = *reinterpret_cast<const bf16x8 *>(a.q + (int64_t)qrow_c * a.ldq + a.q_col + head * 128 + 32 * s + 8 * g);
-  const int kend = (t * 16 + 16 < a.P ? t * 16 + 16 : a.P);  // keys [0, kend) are visible to some row of this tile
+  const int kend_wg = (t_top * 16 + 16 < a.P ? t_top * 16 + 16 : a.P);  // keys [0, kend) are visible to some row of the tile
+  const int ntile_wg = (kend_wg + 31) >> 5;
+  const int kend = t < 0 ? 0 : (t * 16 + 16 < a.P ? t * 16 + 16 : a.P);
   const int ntile = (kend + 31) >> 5;
-  // tile fetch: K fragments (lane: key u*16 + qi, d = 32 s + 8 g ..) and the V rows (chunk c = l + 64 i of the 32 x 16
-  // 16-byte chunks); rows past the last prompt row are clamped (their scores are masked, their V rows never read)
-  auto fetch = [&](bf16x8(&kf)[2][4], bf16x8(&vr)[8], int tile) {
-    const int key0 = tile * 32;
+  // this wave's share of a stage: the 1 KiB requests (4 rows each) w, w + PA_NW, .. < 8 of the K tile and of the V tile; rows past
+  // the last prompt row are clamped (their scores are masked); past the last tile the last tile is requested again, so
+  // that the number of requests in flight is the same in every iteration
+  auto stage = [&](int tile) {
+    const int tl = tile < ntile_wg ? tile : ntile_wg - 1;
+    char *base = &lds[tile % PA_NS][0][0];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      int kr = key0 + u * 16 + qi;
-      kr = kr < a.P ? kr : a.P - 1;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) kf[u][s] = *reinterpret_cast<const bf16x8 *>(K + (int64_t)kr * 128 + 32 * s + 8 * g);
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int c = l + 64 * i;
-      int vrw = key0 + (c >> 4);
-      vrw = vrw < a.P ? vrw : a.P - 1;
-      vr[i] = *reinterpret_cast<const bf16x8 *>(V + (int64_t)vrw * 128 + (c & 15) * 8);
-    }
-  };
-  auto put_v = [&](const bf16x8(&vr)[8]) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int c = l + 64 * i;
-      *reinterpret_cast<bf16x8 *>(my_v + pv_swz(c >> 4, c & 15)) = vr[i];
+    for (int j = 0; j < 8 / PA_NW; ++j) {
+      const int rq = w + j * PA_NW;  // request index within the tile
+      const int rl = rq * 4 + (l >> 4), pc = l & 15;
+      int row = tl * 32 + rl;
+      row = row < a.P ? row : a.P - 1;
+      const int ck = pc ^ (rl & 15);
+      const int cv = ((((pc >> 1) ^ (rl & 7)) << 1) | (pc & 1));
+      __builtin_amdgcn_global_load_lds((glb_void *)(K + (int64_t)row * 128 + ck * 8), (lds_void *)(base + rq * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void *)(V + (int64_t)row * 128 + cv * 8), (lds_void *)(base + 8192 + rq * 1024), 16,
+                                       0, 0);
     }
   };
   f32x4 o[8];
 #pragma unroll
   for (int dt = 0; dt < 8; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
-  auto compute = [&](const bf16x8(&kf)[2][4], int key0) {
+  auto compute = [&](const char *kt, const char *vt, int key0) {
     const int qq = qi >> 2, p4 = l & 3;
-    int vrows = a.P - key0;
-    vrows = vrows > 32 ? 32 : vrows;
-    int r0 = 4 * g + qq, r1 = 16 + 4 * g + qq;
-    r0 = r0 < vrows ? r0 : vrows - 1;  // (rows past the data hold stale LDS bytes: P is 0 there, but 0 x NaN is not)
-    r1 = r1 < vrows ? r1 : vrows - 1;
+    const int r0 = 4 * g + qq, r1 = 16 + 4 * g + qq;
     f32x4 sc[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       sc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s = 0; s < 4; ++s) sc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[u][s], qf[s], sc[u], 0, 0, 0);
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(kt + (u * 16 + qi) * 256 + (((s * 4 + g) ^ qi) << 4));
+        sc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[s], sc[u], 0, 0, 0);
+      }
     }
     float mx = -INFINITY;  // lane (q = qi, g): sc[u][r] is key key0 + u * 16 + 4 g + r
 #pragma unroll
@@ -425,28 +425,57 @@ __global__ __launch_bounds__(256) void k_pattn(PAttnArgs a) {
     l_run = l_run * alpha + psum;
 #pragma unroll
     for (int dt = 0; dt < 8; ++dt) o[dt] *= alpha;
+    // The transposed V reads go through inline asm: behind the builtin hipcc puts s_waitcnt vmcnt(0) in front of every
+    // ds_read_b64_tr_b16 (an LDS read that "may alias" the LDS-DMA requests in flight — the ring), i.e. the tiles in
+    // flight.  The asm issues the reads of four d tiles and waits for them itself; "memory" keeps the compiler's own LDS
+    // reads (whose lgkmcnt it counts itself) on their side of the block.
+    // (rows past the prompt hold copies of its last row: finite values under P = 0)
+    const unsigned vb = (unsigned)(uintptr_t)(plds_bf16x4 *)vt;
+    const unsigned a0 = vb + r0 * 256 + (p4 << 3), a1 = vb + r1 * 256 + (p4 << 3);
 #pragma unroll
-    for (int dt = 0; dt < 8; ++dt) {
-      const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((plds_bf16x4 *)(my_v + r0 * 256 + (((dt ^ (r0 & 7)) << 5) | (p4 << 3))));
-      const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((plds_bf16x4 *)(my_v + r1 * 256 + (((dt ^ (r1 & 7)) << 5) | (p4 << 3))));
-      const bf16x8 va = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-      o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb, o[dt], 0, 0, 0);
+    for (int h = 0; h < 2; ++h) {
+      bf16x4 v0[4], v1[4];
+      unsigned ad0[4], ad1[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ad0[i] = a0 + (((h * 4 + i) ^ (r0 & 7)) << 5);
+        ad1[i] = a1 + (((h * 4 + i) ^ (r1 & 7)) << 5);
+      }
+      asm volatile(
+          "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %12\n\t"
+          "ds_read_b64_tr_b16 %2, %9\n\tds_read_b64_tr_b16 %3, %13\n\t"
+          "ds_read_b64_tr_b16 %4, %10\n\tds_read_b64_tr_b16 %5, %14\n\t"
+          "ds_read_b64_tr_b16 %6, %11\n\tds_read_b64_tr_b16 %7, %15\n\t"
+          "s_waitcnt lgkmcnt(0)"
+          : "=&v"(v0[0]), "=&v"(v1[0]), "=&v"(v0[1]), "=&v"(v1[1]), "=&v"(v0[2]), "=&v"(v1[2]), "=&v"(v0[3]), "=&v"(v1[3])
+          : "v"(ad0[0]), "v"(ad0[1]), "v"(ad0[2]), "v"(ad0[3]), "v"(ad1[0]), "v"(ad1[1]), "v"(ad1[2]), "v"(ad1[3])
+          : "memory");
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bf16x8 va = {v0[i][0], v0[i][1], v0[i][2], v0[i][3], v1[i][0], v1[i][1], v1[i][2], v1[i][3]};
+        o[h * 4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb, o[h * 4 + i], 0, 0, 0);
+      }
     }
   };
-  // the walk: every fetch unconditional (past the last tile: the last tile once more), so that hipcc can count the loads
-  // in flight instead of waiting vmcnt(0) behind a conditional request (csrc/attn_head.hip)
-  bf16x8 kA[2][4], kB[2][4], vA[8], vB[8];
-  fetch(kA, vA, 0);
-  for (int tc = 0; tc < ntile; tc += 2) {
-    fetch(kB, vB, tc + 1 < ntile ? tc + 1 : ntile - 1);
-    put_v(vA);
-    compute(kA, tc * 32);
-    fetch(kA, vA, tc + 2 < ntile ? tc + 2 : ntile - 1);
-    if (tc + 1 < ntile) {
-      put_v(vB);
-      compute(kB, (tc + 1) * 32);
-    }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the q fragments: from here on vmcnt counts ring requests only
+#pragma unroll
+  for (int i = 0; i < PA_NS - 1; ++i) stage(i);
+  for (int tc = 0; tc < ntile_wg; ++tc) {
+    // this wave's requests of tile tc have landed (16 / PA_NW per stage, PA_NS - 2 later stages may still be in flight) ...
+    if (PA_NW == 8)
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    static_assert(PA_NS == 4 && (PA_NW == 4 || PA_NW == 8), "vmcnt immediates above = (16 / PA_NW) * (PA_NS - 2)");
+    // ... and every wave's; every wave is done with tile tc - 1, whose stage the next request overwrites.  A bare
+    // s_barrier: __syncthreads() carries a fence, i.e. vmcnt(0) — the tiles in flight.
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    stage(tc + PA_NS - 1);
+    if (tc < ntile) compute(&lds[tc % PA_NS][0][0], &lds[tc % PA_NS][1][0], tc * 32);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (requests of the tail still target this workgroup's LDS)
+  if (t < 0) return;
   // O^T tile dt: lane (q = qi, g) holds d = dt * 16 + 4 g + r  ->  frag16: column k = head * 128 + d of row tile t
   const float inv = 1.f / pg_sum(l_run);
   bf16x8 *base = a.out_frag + (size_t)t * a.KSo * 64;
@@ -735,11 +764,12 @@ extern "C" int dfl_prefill_attn(const void *q_rows, int64_t ldq, int q_col, cons
               "dfl_prefill_attn: bad shape (P=%d cache_rows=%d n_q=%d n_kv=%d)", P, cache_rows, n_q, n_kv);
   const int G = n_q / n_kv;
   int hq = G % 4 == 0 ? 4 : (G % 2 == 0 ? 2 : 1);
-  // (measured, 8B shapes, whole prefill: P = 1024 20.85 ms either way; P = 4096, 12 layers: 33.0 -> 28.3 ms)
+  // (measured, 8B shapes, whole prefill, with the first form of k_pattn: P = 1024 20.85 ms either way; P = 4096, 12 layers:
+  // 33.0 -> 28.3 ms; then the shared K / V ring: 19.7 / 24.8 ms with 4-wave workgroups, 19.3 / 23.6 ms with 8 waves)
   PAttnArgs a{(const bf16_t *)q_rows, ldq, q_col, (const bf16_t *)kcache, (const bf16_t *)vcache, cache_rows, P, G,
               scale * 1.4426950408889634f, (bf16x8 *)out_frag, n_q * 4, hq};
-  const int nqt = (P + 15) / 16, per = 4 / hq;
-  hipLaunchKernelGGL(k_pattn, dim3((nqt + per - 1) / per, n_q / hq), dim3(256), 0, (hipStream_t)stream, a);
+  const int nqt = (P + 15) / 16, per = PA_NW / hq;
+  hipLaunchKernelGGL(k_pattn, dim3((nqt + per - 1) / per, n_q / hq), dim3(64 * PA_NW), 0, (hipStream_t)stream, a);
   DFL_CHECK_LAUNCH("dfl_prefill_attn");
   return DFL_OK;
 }
