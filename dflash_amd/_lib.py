@@ -79,6 +79,7 @@ SIGNATURES = {
     "dfl_prefill_gemm_resid": (_i, [_p, _p, _i, _i, _i, _p, _i64, _p, _i64, _p]),
     "dfl_prefill_gemm_silu": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "dfl_prefill_norm_pack": (_i, [_p, _i64, _i, _i, _p, _f, _p, _p]),
+    "dfl_prefill_pack_rows": (_i, [_p, _i64, _i, _i, _p, _p]),
     "dfl_prefill_qk_rope": (_i, [_p, _i64, _i, _i, _i, _i, _i, _i, _p, _p, _f, _p, _p, _i, _i, _p, _p, _i, _i, _p]),
     "dfl_prefill_attn": (_i, [_p, _i64, _i, _p, _p, _i, _i, _i, _i, _f, _p, _p]),
     "dfl_prefill_moe_max_tiles": (_i64, [_i, _i, _i]),

@@ -199,12 +199,13 @@ __global__ __launch_bounds__(256) void k_pgemm(PGemmArgs a) {
 // form, one workgroup per 16-row tile with 16 threads per row, took 22 us for 1024 x 4096: 64 workgroups, two passes).
 // norm_w == nullptr: pack only.  Rows >= P give zero fragments.  H <= 64 * 8 * PN_MAXC.
 constexpr int PN_MAXC = 8;
+// ks_total / ks0: the tiles' k-step count and the k-step these H columns start at (a column chunk of wider rows).
 __global__ __launch_bounds__(256) void k_pnorm_pack(const bf16_t *h, int64_t ldh, int P, int H, const bf16_t *norm_w,
-                                                    float eps, bf16x8 *xf) {
+                                                    float eps, bf16x8 *xf, int ks_total, int ks0) {
   const int mt = blockIdx.x, l = threadIdx.x & 63;
   const int m = blockIdx.y * 4 + (threadIdx.x >> 6);
   const int row = mt * 16 + m;
-  const int KS = H >> 5, nch = H >> 3;
+  const int nch = H >> 3;
   const bf16_t *src = h + (int64_t)row * ldh;
   bf16x8 v[PN_MAXC];
   float ss = 0.f;
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(256) void k_pnorm_pack(const bf16_t *h, int64_t ldh
   }
   float rstd = 1.f;
   if (norm_w) rstd = rsqrtf(wave_sum(ss) / (float)H + eps);
-  bf16x8 *dst = xf + (size_t)mt * KS * 64;
+  bf16x8 *dst = xf + ((size_t)mt * ks_total + ks0) * 64;
 #pragma unroll
   for (int i = 0; i < PN_MAXC; ++i) {
     const int c = l + 64 * i;
@@ -293,12 +294,7 @@ __global__ __launch_bounds__(256) void k_pqk_rope(PRopeArgs a) {
 }
 
 // Causal attention of the prompt over itself (tf:modeling_qwen3.py eager / SDPA attention of the target's prefill
-// forward, model/dflash.py:218-225): softmax(q k^T * scale, causal) v per query head, GQA.  One WAVE per (query head,
-// 16-row query tile), no barrier anywhere: the wave walks its 32-key tiles up to the diagonal with the next tile in
-// flight — K fragments L2 -> VGPR directly in MFMA A-operand order, V rows through a wave-private 8 KB LDS tile for
-// ds_read_b64_tr_b16 — S^T = K Q^T and O^T += V^T P^T on v_mfma_f32_16x16x32_bf16 with the base-2 online softmax of
-// csrc/attn_head.hip (same fragment layouts; P rounded to bf16 for the PV product).  The four waves of a workgroup take
-// four consecutive query tiles of one head (the same K/V rows, from L1 / L2); heavy tiles (late rows) are dealt first.
+// forward, model/dflash.py:218-225): softmax(q k^T * scale, causal) v per query head, GQA (kernel: k_pattn below).
 // q: post-norm, post-RoPE bf16 rows (dfl_prefill_qk_rope rewrote them in place); K/V: the cache rows it wrote.
 // Output: frag16 row tiles of n_q * 128 columns — o_proj's operand, no pack step in between.
 struct PAttnArgs {
@@ -736,8 +732,20 @@ extern "C" int dfl_prefill_norm_pack(const void *h, int64_t ldh, int P, int H, c
               "dfl_prefill_norm_pack: bad shape (H %% 32, H <= %d)", 64 * 8 * PN_MAXC);
   const int mtiles = (P + 127) / 128 * 8;  // the padded row tiles are written too (zero fragments)
   hipLaunchKernelGGL(k_pnorm_pack, dim3(mtiles, 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)h, ldh, P, H,
-                     (const bf16_t *)norm_w, eps, (bf16x8 *)x_frag);
+                     (const bf16_t *)norm_w, eps, (bf16x8 *)x_frag, H / 32, 0);
   DFL_CHECK_LAUNCH("dfl_prefill_norm_pack");
+  return DFL_OK;
+}
+
+extern "C" int dfl_prefill_pack_rows(const void *rows, int64_t ld, int P, int K, void *x_frag, void *stream) {
+  DFL_REQUIRE(rows && x_frag && P >= 1 && K > 0 && K % 32 == 0 && ld >= K && ld % 8 == 0, "dfl_prefill_pack_rows: bad shape (K %% 32)");
+  const int mtiles = (P + 127) / 128 * 8, chunk = 64 * 8 * PN_MAXC;
+  for (int c0 = 0; c0 < K; c0 += chunk) {  // (a wave keeps at most `chunk` columns of its row in registers)
+    const int hc = K - c0 < chunk ? K - c0 : chunk;
+    hipLaunchKernelGGL(k_pnorm_pack, dim3(mtiles, 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)rows + c0, ld, P, hc,
+                       (const bf16_t *)nullptr, 0.f, (bf16x8 *)x_frag, K / 32, c0 / 32);
+  }
+  DFL_CHECK_LAUNCH("dfl_prefill_pack_rows");
   return DFL_OK;
 }
 
@@ -746,7 +754,7 @@ extern "C" int dfl_prefill_qk_rope(void *qkv_rows, int64_t ld, int P, int q_col,
                                    const void *sin_tab, int max_pos, int pos0, void *kcache, void *vcache,
                                    int cache_rows, int row0, void *stream) {
   DFL_REQUIRE(qkv_rows && cos_tab && sin_tab && kcache && vcache, "dfl_prefill_qk_rope: null pointer");
-  DFL_REQUIRE(P >= 1 && n_q >= 1 && n_kv >= 1 && max_pos >= 1 && pos0 >= 0 && row0 >= 0 && row0 + P <= cache_rows,
+  DFL_REQUIRE(P >= 1 && n_q >= 0 && n_kv >= 1 && max_pos >= 1 && pos0 >= 0 && row0 >= 0 && row0 + P <= cache_rows,
               "dfl_prefill_qk_rope: bad lengths (P=%d row0=%d cache_rows=%d)", P, row0, cache_rows);
   PRopeArgs a{(bf16_t *)qkv_rows, ld, P, q_col, k_col, v_col, n_q, n_kv, (const bf16_t *)q_norm_w,
               (const bf16_t *)k_norm_w, eps, (const bf16_t *)cos_tab, (const bf16_t *)sin_tab, max_pos, pos0,

@@ -101,6 +101,7 @@ class DFlashDraftModel:
         self.lm_head_events_log = None  # a list: every pair actually recorded is appended (a run-ahead draft uses the
         #                                 pair of the cycle in which it is ENQUEUED)
         self.wide_prefill = True   # False: the round-1 context prefill in 16-row groups (kept for A/B timing and tests)
+        self.rows_prefill = True   # False: prompts of >= 128 context rows go 64 at a time (round 2) instead of at once
 
     # ------------------------------------------------------------------ weights
     def eval(self):
@@ -285,6 +286,29 @@ class DFlashDraftModel:
                                 sin_tab=sin, kcache=cache.k, vcache=cache.v, dyn=p["dyn"])
         cache.length = S + n
 
+    def _prefill_context_rows(self, cache: DFlashKVCache, th: torch.Tensor, pos0: int) -> None:
+        """A whole prompt's context rows at once on the prefill kernels (csrc/prefill.hip, model/dflash.py:73-85 for
+        ctx = P rows): fc as one prompt-length MFMA GEMM (K = 5 H tapped states per row), hidden_norm + pack, ONE k/v GEMM
+        for the five layers, then k-norm + RoPE + cache write per layer — the same roundings as the tile-by-tile forms
+        (Linear outputs in bf16), 13 launches for any P (P = 1024: 0.5 ms instead of 1.7 ms in 80 launches)."""
+        c, w = self.config, self.w
+        H, L, n, S = c.hidden_size, c.num_hidden_layers, th.shape[0], cache.length
+        nkv = L * 2 * c.kv_dim
+        Pp = ops.prefill_rows_padded(n)
+        r = getattr(self, "_rws", None)
+        if r is None or r["h"].shape[0] < Pp:
+            z = lambda *s_: torch.zeros(*s_, dtype=BF16, device=self.device)  # noqa: E731
+            r = self._rws = dict(xf=z(Pp * c.fc_in), h=z(Pp, H), xn=z(Pp * H), kv=z(Pp, nkv))
+        cos, sin = self._rope_tab(pos0 + n + 64)
+        ops.prefill_pack_rows(th, n, c.fc_in, r["xf"])
+        ops.prefill_gemm_rows(w["fc"], r["xf"], n, H, c.fc_in, r["h"])
+        ops.prefill_norm_pack(r["h"], n, H, w["hidden_norm"], c.rms_norm_eps, r["xn"])
+        ops.prefill_gemm_rows(w["kv_all"], r["xn"], n, nkv, H, r["kv"])
+        for i, lw in enumerate(w["layers"]):
+            ops.prefill_qk_rope(r["kv"], n, 0, i * 2 * c.kv_dim, i * 2 * c.kv_dim + c.kv_dim, 0, c.num_key_value_heads, None,
+                                lw["k_norm"], c.rms_norm_eps, cos, sin, pos0, cache.k[i], cache.v[i], S)
+        cache.length = S + n
+
     def prefill_context(self, cache: DFlashKVCache, target_hidden: torch.Tensor, pos0: int) -> None:
         """Append K/V of `target_hidden` rows (context only, no block) to the cache at
         rows/positions cache.length...  Cycle 0 of the reference projects the P prompt rows
@@ -299,6 +323,9 @@ class DFlashDraftModel:
         S = cache.length
         if S + n > cache.max_rows:
             raise ValueError("draft KV cache too small")
+        if (n >= 128 and self.rows_prefill and c.hidden_size % 128 == 0 and c.fc_in % 64 == 0
+                and (c.num_hidden_layers * 2 * c.kv_dim) % 128 == 0 and "kv_all" in self.w):
+            return self._prefill_context_rows(cache, th.contiguous(), pos0)
         if n > 16 and self.wide_prefill:
             return self._prefill_context_wide(cache, th, pos0)
         cos, sin = self._rope_tab(pos0 + n + 64)

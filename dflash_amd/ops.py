@@ -667,6 +667,13 @@ def prefill_norm_pack(h: torch.Tensor, P: int, H: int, norm_w, eps: float, x_fra
                                       _p(x_frag, BF16, "x_frag"), _stream()), "dfl_prefill_norm_pack")
 
 
+def prefill_pack_rows(rows: torch.Tensor, P: int, K: int, x_frag: torch.Tensor) -> None:
+    """rows [P, K] -> frag16 row tiles (any K % 32 == 0), no norm."""
+    assert rows.dtype == BF16 and rows.stride(1) == 1 and rows.shape[0] >= P and x_frag.numel() >= prefill_rows_padded(P) * K
+    check(lib().dfl_prefill_pack_rows(rows.data_ptr(), rows.stride(0), P, K, _p(x_frag, BF16, "x_frag"), _stream()),
+          "dfl_prefill_pack_rows")
+
+
 def prefill_qk_rope(qkv: torch.Tensor, P: int, q_col: int, k_col: int, v_col: int, n_q: int, n_kv: int, q_norm_w,
                     k_norm_w, eps: float, cos_tab, sin_tab, pos0: int, kcache, vcache, row0: int) -> None:
     assert qkv.dtype == BF16 and qkv.stride(1) == 1 and kcache.shape == vcache.shape and kcache.shape[2] == 128

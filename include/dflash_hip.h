@@ -372,6 +372,9 @@ int dfl_prefill_gemm_silu(const void *wp_gateup, const void *x_frag, int P, int 
  * tiles of H columns; all dfl_prefill_rows_padded(P) / 16 tiles are written (zero fragments beyond row P). */
 int dfl_prefill_norm_pack(const void *h, int64_t ldh, int P, int H, const void *norm_w, float eps, void *x_frag,
                           void *stream);
+/* rows [P][K] (row stride ld) -> frag16 row tiles of K columns, any K % 32 == 0 (the draft's fc operand: K = 5 H tapped
+ * states per prompt row, model/dflash.py:166-171); no norm. */
+int dfl_prefill_pack_rows(const void *rows, int64_t ld, int P, int K, void *x_frag, void *stream);
 
 /* Per-head q/k RMSNorm (weights may be NULL: Llama) + RoPE at positions pos0 + row over the P rows of a bf16 q/k/v row
  * buffer (row stride ld): q is rewritten in place, k (normed, rotated) and v go to cache rows row0 + row of

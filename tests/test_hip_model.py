@@ -831,11 +831,11 @@ def test_native_target_wide_blocks_lossless_walk():
     assert set(rp.used_block_sizes) & {20, 24}
 
 
-@pytest.mark.parametrize("P", [17, 64, 100, 1000])
+@pytest.mark.parametrize("P", [17, 64, 100, 128, 300, 1000])
 def test_wide_context_prefill_equals_group_prefill(P):
-    """The prompt's context rows through the 64-row passes of the ragged-batch GEMMs (model/dflash.py:73-85 at ctx = P)
-    vs the 16-row-group path: the same K/V rows in every layer (V up to the rounding of a different K-split order, K
-    likewise after its RoPE), both within tolerance of the oracle on the CPU."""
+    """The prompt's context rows at once on the prefill kernels (P >= 128) / through the 64-row passes of the ragged-batch
+    GEMMs (model/dflash.py:73-85 at ctx = P) vs the 16-row-group path: the same K/V rows in every layer (V up to the
+    rounding of a different K-split order, K likewise after its RoPE), within tolerance of the oracle on the CPU."""
     from oracle import dflash_oracle as O
     cfg = H.tiny_cfg()
     m = make_model(cfg)
@@ -848,11 +848,19 @@ def test_wide_context_prefill_equals_group_prefill(P):
     m.prefill_context(cb, th[0].to(dev()), 5)
     m.wide_prefill = True
     assert ca.get_seq_length() == cb.get_seq_length() == P
+    if P >= 128:      # ca took the prompt-length kernels: the 64-row passes are the third form
+        cc = m.new_cache(P + 64)
+        m.rows_prefill = False
+        m.prefill_context(cc, th[0].to(dev()), 5)
+        m.rows_prefill = True
+        for li in range(cfg.num_hidden_layers):
+            H.assert_close(f"64-row passes K l{li} P{P}", cc.k[li][:, :P], cb.k[li][:, :P], max_rel=2 ** -6, mean_rel=1e-3)
+            H.assert_close(f"64-row passes V l{li} P{P}", cc.v[li][:, :P], cb.v[li][:, :P], max_rel=2 ** -6, mean_rel=1e-3)
     for li in range(cfg.num_hidden_layers):
         H.assert_close(f"wide prefill K l{li} P{P}", ca.k[li][:, :P], cb.k[li][:, :P], max_rel=2 ** -6, mean_rel=1e-3)
         H.assert_close(f"wide prefill V l{li} P{P}", ca.v[li][:, :P], cb.v[li][:, :P], max_rel=2 ** -6, mean_rel=1e-3)
     assert int(torch.count_nonzero(ca.k[:, :, P:])) == 0 and int(torch.count_nonzero(ca.v[:, :, P:])) == 0
-    if P <= 100:   # and against the oracle: K/V of the context rows as the reference caches them (positions 5..)
+    if P <= 300:   # and against the oracle: K/V of the context rows as the reference caches them (positions 5..)
         w = H.draft_weights(cfg, dtype=BF16)
         oc = H.oracle_cfg(cfg, "sdpa")
         oc_cache = O.ListKVCache()
