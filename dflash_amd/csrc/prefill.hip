@@ -43,11 +43,73 @@ struct PGemmArgs {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
+// The epilogues of k_pgemm for one wave: acc[i][j] = n tile nb * 8 + wn * 4 + i x row tile tile0 + wm * MW + j.
+template <int EPI, int MW, bool GRP>
+__device__ __forceinline__ void pgemm_epilogue(const PGemmArgs &a, f32x4 (&acc)[4][MW], int nb, int wn, int wm, int tile0, int ntl,
+                                               int l) {
+  // D layout (A = W rows n, B = x^T columns m): lane L, register r = column 4 (L >> 4) + r of the n tile, row L & 15
+  const int fm = l & 15, fg = l >> 4;
+#pragma unroll
+  for (int j = 0; j < MW; ++j) {
+    if (GRP && wm * MW + j >= ntl) continue;
+    const int mt = tile0 + wm * MW + j;
+    const int m = mt * 16 + fm;
+    if (EPI == PEPI_SILU) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {  // (gate, up) tile pairs: tf:modeling_qwen3.py:82, rounded where torch rounds
+        const int pair = (nb * 8 + wn * 4) / 2 + q;
+        const int n0 = pair * 16 + 4 * fg;
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float gb = rbf(acc[2 * q][j][r]), ub = rbf(acc[2 * q + 1][j][r]);
+          const float act = rbf(gb / (1.f + __expf(-gb)));
+          o[r] = f2bf(act * ub);
+        }
+        bf16_t *dst = reinterpret_cast<bf16_t *>(a.act + ((size_t)mt * a.KSo + (n0 >> 5)) * 64 + ((n0 >> 3) & 3) * 16 + fm) + (n0 & 7);
+        *reinterpret_cast<bf16x4 *>(dst) = o;
+      }
+    } else if (EPI == PEPI_SCALE32) {  // an expert's down projection: scaled by the row's routing weight, kept fp32
+      const float rw = a.row_w[m];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int n0 = (nb * 8 + wn * 4 + i) * 16 + 4 * fg;
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = rw * acc[i][j][r];
+        *reinterpret_cast<f32x4 *>(a.out32 + (int64_t)m * a.ld32 + n0) = o;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int n0 = (nb * 8 + wn * 4 + i) * 16 + 4 * fg;
+        if (m < a.P) {
+          bf16_t *dst = a.out + (int64_t)m * a.ldo + n0;
+          bf16x4 o;
+          if (EPI == PEPI_RESID) {  // model/dflash.py:140,144 form of the residual add: bf16 + bf16 -> bf16
+            const bf16x4 hv = *reinterpret_cast<const bf16x4 *>(dst);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = f2bf(rbf(bf2f(hv[r]) + rbf(acc[i][j][r])));
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = f2bf(acc[i][j][r]);
+          }
+          *reinterpret_cast<bf16x4 *>(dst) = o;
+          if (EPI == PEPI_RESID && a.tap) *reinterpret_cast<bf16x4 *>(a.tap + (int64_t)m * a.ldtap + n0) = o;
+        }
+      }
+    }
+  }
+}
+
 // MW = row tiles per wave: 4 -> block tile 128 columns x 128 rows; 2 -> 128 x 64 (twice the workgroups: the N = 4096
 // projections o_proj / down_proj have only 32 column blocks, and ONE 4-wave workgroup per CU leaves the matrix pipe idle
 // whenever it waits for its own LDS-DMA: 115 -> see DESIGN.md for the measured step)
 // NST = LDS stages: NST - 1 in flight while one is in the MFMAs (two workgroups per CU up to 80 KiB each).
-// GRP: the grouped form (64-row blocks): blockIdx.x = item * column blocks + column block.
+// GRP: the grouped form: the work items are dealt round-robin to the XCDs, an item's column blocks stay on one.
+// (Tried for the grouped form and dropped, commit history: rings of their own for the two operands — five 16 KB weight
+// stages from HBM and three activation stages from L2, fed by different waves so that the in-order vmcnt of a wave
+// tracks one ring, ONE workgroup per CU: 607 us per 30B-A3B layer against 449 for this kernel with two workgroups per CU.)
 template <int EPI, int MW, int NST, bool GRP = false>
 __global__ __launch_bounds__(256) void k_pgemm(PGemmArgs a) {
   constexpr int MB = 2 * MW;  // row tiles per block
@@ -63,8 +125,11 @@ __global__ __launch_bounds__(256) void k_pgemm(PGemmArgs a) {
   int nb, mb = 0, tile0 = 0, ntl = MB;
   const bf16x8 *wbase = a.wp;
   if (GRP) {
-    const int item = blockIdx.x / nbx;
-    nb = blockIdx.x - item * nbx;
+    // the column blocks of an item share blockIdx % 8, i.e. an XCD and its L2: the item's gathered rows leave HBM once
+    // (first form, blockIdx = item * nbx + nb: the 12 column blocks of an item sat on 8 XCDs and every one of those
+    // L2s fetched the rows for itself)
+    const int seq = blockIdx.x >> 3, item = (seq / nbx) * 8 + (blockIdx.x & 7);
+    nb = seq % nbx;
     if (item >= *a.n_items) return;  // (uniform: the grid is sized for the worst case)
     wbase += (int64_t)a.items[3 * item] * a.w_expert_stride;
     tile0 = a.items[3 * item + 1];
@@ -139,59 +204,7 @@ __global__ __launch_bounds__(256) void k_pgemm(PGemmArgs a) {
     buf = buf == NST - 1 ? 0 : buf + 1;
   }
 
-  // D layout (A = W rows n, B = x^T columns m): lane L, register r = column 4 (L >> 4) + r of the n tile, row L & 15
-  const int fm = l & 15, fg = l >> 4;
-#pragma unroll
-  for (int j = 0; j < MW; ++j) {
-    if (GRP && wm * MW + j >= ntl) continue;
-    const int mt = tile0 + wm * MW + j;
-    const int m = mt * 16 + fm;
-    if (EPI == PEPI_SILU) {
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {  // (gate, up) tile pairs: tf:modeling_qwen3.py:82, rounded where torch rounds
-        const int pair = (nb * 8 + wn * 4) / 2 + q;
-        const int n0 = pair * 16 + 4 * fg;
-        bf16x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float gb = rbf(acc[2 * q][j][r]), ub = rbf(acc[2 * q + 1][j][r]);
-          const float act = rbf(gb / (1.f + __expf(-gb)));
-          o[r] = f2bf(act * ub);
-        }
-        bf16_t *dst = reinterpret_cast<bf16_t *>(a.act + ((size_t)mt * a.KSo + (n0 >> 5)) * 64 + ((n0 >> 3) & 3) * 16 + fm) + (n0 & 7);
-        *reinterpret_cast<bf16x4 *>(dst) = o;
-      }
-    } else if (EPI == PEPI_SCALE32) {  // an expert's down projection: scaled by the row's routing weight, kept fp32
-      const float rw = a.row_w[m];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int n0 = (nb * 8 + wn * 4 + i) * 16 + 4 * fg;
-        f32x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = rw * acc[i][j][r];
-        *reinterpret_cast<f32x4 *>(a.out32 + (int64_t)m * a.ld32 + n0) = o;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int n0 = (nb * 8 + wn * 4 + i) * 16 + 4 * fg;
-        if (m < a.P) {
-          bf16_t *dst = a.out + (int64_t)m * a.ldo + n0;
-          bf16x4 o;
-          if (EPI == PEPI_RESID) {  // model/dflash.py:140,144 form of the residual add: bf16 + bf16 -> bf16
-            const bf16x4 hv = *reinterpret_cast<const bf16x4 *>(dst);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = f2bf(rbf(bf2f(hv[r]) + rbf(acc[i][j][r])));
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = f2bf(acc[i][j][r]);
-          }
-          *reinterpret_cast<bf16x4 *>(dst) = o;
-          if (EPI == PEPI_RESID && a.tap) *reinterpret_cast<bf16x4 *>(a.tap + (int64_t)m * a.ldtap + n0) = o;
-        }
-      }
-    }
-  }
+  pgemm_epilogue<EPI, MW, GRP>(a, acc, nb, wn, wm, tile0, ntl, l);
 }
 
 // rows [P][H] -> (RMSNorm) -> frag16 row tiles.  One WAVE per row (grid = row tiles x 4, four rows per workgroup): the
@@ -829,10 +842,11 @@ extern "C" int dfl_prefill_moe_gemm_silu(const void *wp_gateup_e, int64_t w_expe
     return DFL_EINVAL;
   a.act = (bf16x8 *)act_g;
   a.KSo = I / 32;
+  const dim3 grid((max_items + 7) / 8 * 8 * (a.ntiles / 8));
   if (rows_per_item == 128)
-    hipLaunchKernelGGL((k_pgemm<PEPI_SILU, 4, 2, true>), dim3(max_items * (a.ntiles / 8)), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((k_pgemm<PEPI_SILU, 4, 2, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
   else
-    hipLaunchKernelGGL((k_pgemm<PEPI_SILU, 2, 3, true>), dim3(max_items * (a.ntiles / 8)), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((k_pgemm<PEPI_SILU, 2, 3, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
   DFL_CHECK_LAUNCH("dfl_prefill_moe_gemm_silu");
   return DFL_OK;
 }
@@ -848,10 +862,11 @@ extern "C" int dfl_prefill_moe_gemm_down(const void *wp_down_e, int64_t w_expert
   a.row_w = row_w;
   a.out32 = out32;
   a.ld32 = H;
+  const dim3 grid((max_items + 7) / 8 * 8 * (a.ntiles / 8));
   if (rows_per_item == 128)
-    hipLaunchKernelGGL((k_pgemm<PEPI_SCALE32, 4, 2, true>), dim3(max_items * (a.ntiles / 8)), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((k_pgemm<PEPI_SCALE32, 4, 2, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
   else
-    hipLaunchKernelGGL((k_pgemm<PEPI_SCALE32, 2, 3, true>), dim3(max_items * (a.ntiles / 8)), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((k_pgemm<PEPI_SCALE32, 2, 3, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
   DFL_CHECK_LAUNCH("dfl_prefill_moe_gemm_down");
   return DFL_OK;
 }
