@@ -355,9 +355,11 @@ __global__ __launch_bounds__(64 * PA_NW) void k_pattn(PAttnArgs a) {
   const int tid = threadIdx.x;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l = tid & 63, qi = l & 15, g = l >> 4;
-  const int head = blockIdx.y * a.hq + w % a.hq;
+  // blockIdx.x = head group (the fast index: with 8 head groups a kv head's workgroups share an XCD and its L2),
+  // blockIdx.y = query tile group
+  const int head = blockIdx.x * a.hq + w % a.hq;
   const int nqt = (a.P + 15) >> 4;
-  const int t_top = nqt - 1 - (int)blockIdx.x * (PA_NW / a.hq);  // the workgroup's longest query tile (late tiles first)
+  const int t_top = nqt - 1 - (int)blockIdx.y * (PA_NW / a.hq);  // the workgroup's longest query tile (late tiles first)
   const int t = t_top - w / a.hq;                                // this wave's; < 0: no tile (it still feeds the ring)
   const bf16_t *K = a.kc + (int64_t)(head / a.G) * a.cache_rows * 128;
   const bf16_t *V = a.vc + (int64_t)(head / a.G) * a.cache_rows * 128;
@@ -790,7 +792,7 @@ extern "C" int dfl_prefill_attn(const void *q_rows, int64_t ldq, int q_col, cons
   PAttnArgs a{(const bf16_t *)q_rows, ldq, q_col, (const bf16_t *)kcache, (const bf16_t *)vcache, cache_rows, P, G,
               scale * 1.4426950408889634f, (bf16x8 *)out_frag, n_q * 4, hq};
   const int nqt = (P + 15) / 16, per = PA_NW / hq;
-  hipLaunchKernelGGL(k_pattn, dim3((nqt + per - 1) / per, n_q / hq), dim3(64 * PA_NW), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(k_pattn, dim3(n_q / hq, (nqt + per - 1) / per), dim3(64 * PA_NW), 0, (hipStream_t)stream, a);
   DFL_CHECK_LAUNCH("dfl_prefill_attn");
   return DFL_OK;
 }
