@@ -193,6 +193,8 @@ def gpu_leg(args, rank, world, dev):
         a.record()
         b.record()
     native = not args.hf_verify
+    if args.graph:   # A/B: the steady-state cycle as two hipGraph replays (DecodeSession.capture), captured before the timed region
+        s.capture(bs)
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -204,6 +206,9 @@ def gpu_leg(args, rank, world, dev):
     # ~0.9 % of the cycle they were meant to observe.  The cycle after an instrumented one only collects the pairs of
     # the draft forward that was enqueued ahead of it.
     E = max(1, args.event_every)
+    if args.graph:
+        E = max(E, args.steps)   # ONE eager, instrumented cycle; the others are replayed
+    s.host_times = []
     for i in range(args.steps):
         instr = i % E == 0
         s.events = {} if (instr or (i - 1) % E == 0) else None
@@ -211,7 +216,8 @@ def gpu_leg(args, rank, world, dev):
         draft.lm_head_events = lm_ev[i] if instr else None
         if native:
             target.gu_events = (i % args.target_layers, gu_ev[i][0], gu_ev[i][1]) if instr else None
-        r = s.cycle(bs, ahead_ok=True)   # fixed block size: the next cycle's draft is enqueued behind this cycle's accept
+        # fixed block size: the next cycle's draft is enqueued behind this cycle's accept
+        r = s.cycle_graph(bs) if (args.graph and s.events is None) else s.cycle(bs, ahead_ok=True)
         if s.events:
             ev_all.append(s.events)
         tokens += r.tau
@@ -220,6 +226,9 @@ def gpu_leg(args, rank, world, dev):
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
     s.events, s.record_events = None, True
+    host_enq = sum(a for a, _ in s.host_times) / max(1, len(s.host_times))
+    host_wait = sum(b for _, b in s.host_times) / max(1, len(s.host_times))
+    s.host_times = None
     draft.lm_head_events = None
     if native:
         target.gu_events = None
@@ -293,6 +302,11 @@ def gpu_leg(args, rank, world, dev):
                   "achieved_GBps": hot_bytes / (draft_ms * 1e-3) / 1e9,
                   "frac_of_8TBps": hot_bytes / (draft_ms * 1e-3) / 1e9 / 8000.0},
         ttft_side=ttft_side,
+        host_side={"enqueue_ms_per_cycle": 1e3 * host_enq, "poll_wait_ms_per_cycle": 1e3 * host_wait,
+                   "note": "host share of a timed cycle (time.perf_counter inside DecodeSession.cycle): Python + ctypes enqueueing "
+                           "the cycle's ~215 launches (with the run-ahead draft: the NEXT cycle's draft forward included), then "
+                           "polling the pinned result word; the GPU is the bottleneck while enqueue < ms_per_step and the poll "
+                           "wait is the rest of it"},
     )
 
 
@@ -529,8 +543,9 @@ def main():
                     help="R > 1: R requests per GPU decode as one ragged batch sharing the weight stream "
                          "(BASELINE.json configs[2] uses 4); needs the native verify")
     ap.add_argument("--graph", action="store_true",
-                    help="with --requests-per-gpu > 1: replay the cycle as three captured hipGraphs instead of ~300 "
-                         "launches (same GPU time: the launches are not the bottleneck; frees the host core)")
+                    help="replay the steady-state cycle from captured hipGraphs instead of ~215 (N = 1: two graphs) / ~300 "
+                         "(--requests-per-gpu > 1: three graphs) launches per cycle: the host's share of a cycle drops from "
+                         "~2.2 ms to ~0.2 ms; the GPU time is the same or slightly longer (DESIGN.md), so eager is the default")
     ap.add_argument("--hf-verify", action="store_true",
                     help="verify through the HF/PyTorch target forward (round-1 configuration) instead of "
                          "dflash_amd.NativeTarget")
@@ -599,7 +614,7 @@ def main():
                        "target_verify": "hf" if args.hf_verify else "native", "parallelism": f"dp{world}"},
             "mean_acceptance_length": res["mean_tau"], "raw_tau1_value": res["raw_tau1_value"],
             "lossless_fraction": res["lossless_fraction"], "roofline": res["roofline"], "hot_path": res["hot_path"],
-            "ttft_side": res.get("ttft_side"), "cpu_baseline": cpu,
+            "ttft_side": res.get("ttft_side"), "host_side": res.get("host_side"), "cpu_baseline": cpu,
         }
         if rehearsal:
             line["rehearsal"] = "DFL_BENCH_SHARE_GPU=1: all ranks shared cuda:0 over gloo — control flow only, not a measurement"

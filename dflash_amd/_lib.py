@@ -73,6 +73,7 @@ SIGNATURES = {
     "dfl_argmax": (_i, [_p, _i, _i, _i64, _p, _p]),
     "dfl_accept_commit": (_i, [_p, _p, _i, _p, _i64, _p, _p, _i, _p, _p]),
     "dfl_accept_commit_rearm": (_i, [_p, _p, _i, _p, _i64, _p, _p, _i, _p, _p, _i, _i64, _p]),
+    "dfl_accept_commit_rearm_t": (_i, [_p, _p, _i, _p, _i64, _p, _p, _i, _p, _p, _i, _i64, _p, _p]),
     # ---- target prefill
     "dfl_prefill_rows_padded": (_i64, [_i]),
     "dfl_prefill_gemm_rows": (_i, [_p, _p, _i, _i, _i, _p, _i64, _p]),

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void k_argmax(const T *__restrict__ logits, in
 __global__ __launch_bounds__(64) void k_accept_commit(const int64_t *block_ids, const int64_t *posterior, int bs,
                                                       int64_t *output_ids, int64_t output_len, int32_t *dyn,
                                                       const int64_t *stop_ids, int n_stop, int32_t *result,
-                                                      int64_t *next_block, int rearm_n, int64_t mask_id) {
+                                                      int64_t *next_block, int rearm_n, int64_t mask_id, int32_t *dyn_t) {
   const int i = threadIdx.x;
   const int start = dyn[DFL_DYN_START];
   const bool cmp = i < bs - 1;
@@ -97,6 +97,12 @@ __global__ __launch_bounds__(64) void k_accept_commit(const int64_t *block_ids, 
     dyn[DFL_DYN_START] = new_start; // :261
     dyn[DFL_DYN_STOP] |= any_stop ? 1 : 0;
     dyn[DFL_DYN_CYCLE] += 1;
+    if (dyn_t) {  // the block-form record of the NEXT verify (its block size word stays): rows kept = positions = new start
+      dyn_t[DFL_DYN_S] = new_start;
+      dyn_t[DFL_DYN_TAU] = 0;
+      dyn_t[DFL_DYN_POS0] = new_start;
+      dyn_t[DFL_DYN_START] = new_start;
+    }
     if (result) {
       // Hand-over a CPU thread may be polling (pinned host memory): the payload words first, then — behind a
       // system-scope release, so that no store can overtake them — the cycle counter as the LAST word.  The host
@@ -197,7 +203,7 @@ extern "C" int dfl_accept_commit(const int64_t *block_ids, const int64_t *poster
   DFL_REQUIRE(bs >= 1 && bs <= 63, "dfl_accept_commit: bs=%d outside 1..63", bs);
   DFL_REQUIRE(n_stop == 0 || stop_ids, "dfl_accept_commit: n_stop>0 without stop_ids");
   hipLaunchKernelGGL(k_accept_commit, dim3(1), dim3(64), 0, (hipStream_t)stream, block_ids, posterior, bs, output_ids,
-                     output_len, dyn, stop_ids, n_stop, result, (int64_t *)nullptr, 0, (int64_t)0);
+                     output_len, dyn, stop_ids, n_stop, result, (int64_t *)nullptr, 0, (int64_t)0, (int32_t *)nullptr);
   DFL_CHECK_LAUNCH("dfl_accept_commit");
   return DFL_OK;
 }
@@ -210,8 +216,22 @@ extern "C" int dfl_accept_commit_rearm(const int64_t *block_ids, const int64_t *
               rearm_n);
   DFL_REQUIRE(n_stop == 0 || stop_ids, "dfl_accept_commit_rearm: n_stop>0 without stop_ids");
   hipLaunchKernelGGL(k_accept_commit, dim3(1), dim3(64), 0, (hipStream_t)stream, block_ids, posterior, bs, output_ids,
-                     output_len, dyn, stop_ids, n_stop, result, next_block, rearm_n, mask_id);
+                     output_len, dyn, stop_ids, n_stop, result, next_block, rearm_n, mask_id, (int32_t *)nullptr);
   DFL_CHECK_LAUNCH("dfl_accept_commit_rearm");
+  return DFL_OK;
+}
+
+extern "C" int dfl_accept_commit_rearm_t(const int64_t *block_ids, const int64_t *posterior, int bs, int64_t *output_ids,
+                                         int64_t output_len, int32_t *dyn, const int64_t *stop_ids, int n_stop,
+                                         int32_t *result, int64_t *next_block, int rearm_n, int64_t mask_id, int32_t *dyn_t,
+                                         void *stream) {
+  DFL_REQUIRE(block_ids && posterior && output_ids && dyn && next_block && dyn_t, "dfl_accept_commit_rearm_t: null pointer");
+  DFL_REQUIRE(bs >= 1 && bs <= 63 && rearm_n >= 1 && rearm_n <= 64, "dfl_accept_commit_rearm_t: bs=%d rearm_n=%d outside range", bs,
+              rearm_n);
+  DFL_REQUIRE(n_stop == 0 || stop_ids, "dfl_accept_commit_rearm_t: n_stop>0 without stop_ids");
+  hipLaunchKernelGGL(k_accept_commit, dim3(1), dim3(64), 0, (hipStream_t)stream, block_ids, posterior, bs, output_ids,
+                     output_len, dyn, stop_ids, n_stop, result, next_block, rearm_n, mask_id, dyn_t);
+  DFL_CHECK_LAUNCH("dfl_accept_commit_rearm_t");
   return DFL_OK;
 }
 

@@ -433,7 +433,7 @@ def argmax(logits: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def accept_commit(block_ids, posterior, bs: int, output_ids, dyn, stop_ids=None, result=None, rearm=None) -> None:
+def accept_commit(block_ids, posterior, bs: int, output_ids, dyn, stop_ids=None, result=None, rearm=None, dyn_t=None) -> None:
     """result: int32[4] on the GPU, or PINNED host memory (the kernel stores the four words with one 16-byte store, a
     CPU thread may poll them).  rearm = (next_block int64 tensor, n, mask_id): the next cycle's block is written by
     the kernel (dfl_accept_commit_rearm)."""
@@ -452,6 +452,10 @@ def accept_commit(block_ids, posterior, bs: int, output_ids, dyn, stop_ids=None,
     if rearm is not None:
         nb, n, mask_id = rearm
         assert nb.numel() >= n
+        if dyn_t is not None:    # the next verify's block-form record kept on the device too (graph replay)
+            check(lib().dfl_accept_commit_rearm_t(*common, _p(nb, I64, "next_block"), int(n), int(mask_id),
+                                                  _p(dyn_t, I32, "dyn_t"), _stream()), "dfl_accept_commit_rearm_t")
+            return
         check(lib().dfl_accept_commit_rearm(*common, _p(nb, I64, "next_block"), int(n), int(mask_id), _stream()),
               "dfl_accept_commit_rearm")
         return

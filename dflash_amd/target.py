@@ -506,7 +506,7 @@ class NativeTarget:
     @torch.inference_mode()
     def verify(self, block_ids: torch.Tensor, start: int, cache: TargetKVCache, *, tap_layers: Sequence[int] = (),
                temperature: float = 0.0, logits_out: Optional[torch.Tensor] = None,
-               taps_out: Optional[torch.Tensor] = None):
+               taps_out: Optional[torch.Tensor] = None, dyn_lengths: bool = False):
         """block_ids int64 [bs] at positions start..start+bs-1 (cache rows alike), bs <= 32.
         Returns (posterior ids int64 [1, bs], taps bf16 [32, len(tap_layers)*H] or None).
         K/V of all bs rows are written; the caller crops to what it accepts.
@@ -514,7 +514,10 @@ class NativeTarget:
         rows until its next draft; sessions interleaved on one target must not share one).
         logits_out: bf16 [16 * tiles, V].  Blocks of 17..32 rows run as two 16-row tiles: one pass over the
         weights through the ragged-batch GEMMs (`_verify_wide`; an MoE layer's expert MLP per tile), or one launch per
-        tile of every single-request GEMM (wide_one_pass = False); both query tiles share the attention launch."""
+        tile of every single-request GEMM (wide_one_pass = False); both query tiles share the attention launch.
+        dyn_lengths (bs <= 16, attention stage "head"): the launches take S / pos0 from the cache's device record alone
+        (kept by dfl_accept_commit_rearm_t) — `start` is then only an upper bound that sizes the attention's key splits
+        and the RoPE table, and the sequence can be captured into a hipGraph (DecodeSession.capture)."""
         bs = block_ids.numel()
         if bs < 1 or bs > 32:
             raise ValueError("verify takes 1..32 block rows")
@@ -529,7 +532,10 @@ class NativeTarget:
         # the verify's kernels read only the tiles' valid-row counts from the record (the attention takes immediates):
         # it is rewritten when the block size changes, not every cycle
         # — the round-1 fused stage (attn_impl="fused") reads S / TAU / POS0 from the record: rewritten every call there
-        if self.attn_impl != "head" or getattr(cache, "_dyn_bs", None) != bs:
+        if dyn_lengths:
+            if bs > 16 or self.attn_impl != "head" or self.fuse_oproj:
+                raise ValueError("dyn_lengths needs a block of <= 16 rows and the plain 'head' attention stage")
+        elif self.attn_impl != "head" or getattr(cache, "_dyn_bs", None) != bs:
             ops.set_dyn2(cache.dyn, start, 0, bs, start)
             cache._dyn_bs = bs
         dyn = cache.dyn[:8]
@@ -566,7 +572,8 @@ class NativeTarget:
                 kw = dict(xq=ws["xq"], q_col=0, k_col=self.q_dim, v_col=self.q_dim + self.kv_dim, n_q=self.n_q,
                           n_kv=self.n_kv, q_norm_w=lw["q_norm"], k_norm_w=lw["k_norm"], eps=self.eps, cos_tab=cos,
                           sin_tab=sin, kcache=cache.k[i], vcache=cache.v[i], scale=128 ** -0.5, causal=True,
-                          S=start, tau=0, bs=bs, pos0=start, ws=ws["head_ws"], max_splits=self.max_splits)
+                          S=start, tau=0, bs=bs, pos0=start, ws=ws["head_ws"], max_splits=self.max_splits,
+                          dyn=dyn if dyn_lengths else None)
                 if fuse_o:
                     ops.attn_head_oproj(**kw, attn_frag=ws["attn"][0], wo=lw["o"], H=H, h_io=hrow[0],
                                         ss_out=ws["ss_h"][0], sync=ws["sync"])

@@ -345,6 +345,12 @@ int dfl_accept_commit(const int64_t *block_ids, const int64_t *posterior, int bs
 int dfl_accept_commit_rearm(const int64_t *block_ids, const int64_t *posterior, int bs, int64_t *output_ids,
                             int64_t output_len, int32_t *dyn, const int64_t *stop_ids, int n_stop, int32_t *result,
                             int64_t *next_block, int rearm_n, int64_t mask_id, void *stream);
+/* The same, and the block-form length record of the NEXT target verify maintained on the device as well (dyn_t:
+ * S = POS0 = START = new start, TAU = 0; its BS word is left alone): with it a steady-state cycle needs no host-side length
+ * at all — verify and accept can be replayed from a hipGraph (DecodeSession.capture). */
+int dfl_accept_commit_rearm_t(const int64_t *block_ids, const int64_t *posterior, int bs, int64_t *output_ids,
+                              int64_t output_len, int32_t *dyn, const int64_t *stop_ids, int n_stop, int32_t *result,
+                              int64_t *next_block, int rearm_n, int64_t mask_id, int32_t *dyn_t, void *stream);
 
 /* ======================================================================================
  * Target PREFILL on the kernels (model/dflash.py:218-225: target(input_ids, ..., output_hidden_states=True) over the

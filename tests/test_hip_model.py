@@ -870,3 +870,52 @@ def test_wide_context_prefill_equals_group_prefill(P):
         for li in range(cfg.num_hidden_layers):
             H.assert_close(f"wide prefill vs oracle K l{li}", ca.k[li][:, :P], oc_cache.k[li][0][:, :P], max_rel=H.KV_MAX_REL)
             H.assert_close(f"wide prefill vs oracle V l{li}", ca.v[li][:, :P], oc_cache.v[li][0][:, :P], max_rel=H.KV_MAX_REL)
+
+
+def test_graph_replayed_cycles_equal_eager_cycles():
+    """DecodeSession.capture / cycle_graph: the steady-state cycle replayed from two hipGraphs —
+    [verify + accept], [the next cycle's draft + lm_head], every length from the device records the accept kernel keeps
+    (dfl_accept_commit_rearm_t) — commits the same ids with the same acceptance lengths as eager cycles, including an
+    eager cycle in the middle (its accept keeps the target's record too) and the eager tail."""
+    from dflash_amd import NativeTarget
+    from dflash_amd.generate import DecodeSession
+    from dflash_amd.synthetic import greedy_walk, impose_greedy_walk
+    cfg = H.tiny_cfg()
+    hf = _tiny_hf()
+    perm = impose_greedy_walk(hf, seed=8)
+    prompt = torch.randint(0, 2000, (1, 41), generator=torch.Generator().manual_seed(3)).to(dev())
+    n_new = 150
+    G = greedy_walk(perm, prompt, n_new + 60).to(dev())
+    plan = H.make_plan(64, 16, 29)
+
+    def hook(blk, start, call):
+        k = min(plan[call], blk.shape[1] - 1)
+        blk[0, 1:k + 1] = G[start + 1:start + k + 1]
+        if k + 1 < blk.shape[1]:
+            blk[0, k + 1] = (G[start + k + 1] + 1) % 2000
+
+    def run(graph):
+        s = DecodeSession(make_model(cfg), NativeTarget(hf), prompt, mask_token_id=cfg.mask_token_id,
+                          max_new_tokens=n_new, max_block_size=16, stop_token_ids=None, temperature=0.0,
+                          draft_token_hook=hook)
+        s.prefill()
+        taus, replayed = [], 0
+        for i in range(64):
+            if s.start >= s.max_length:
+                break
+            bs = min(16, s.max_length - s.start)
+            if graph and i == 2:
+                s.capture(16)
+            if graph and i >= 2 and i != 5 and bs == 16:
+                replayed += int(s._graph_ok(16))
+                r = s.cycle_graph(16)
+            else:
+                r = s.cycle(bs, ahead_ok=bs == 16)
+            taus.append(r.tau)
+        return s.finish()[0].tolist(), taus, replayed
+
+    ids_e, taus_e, _ = run(False)
+    ids_g, taus_g, replayed = run(True)
+    assert ids_e == G[:41 + n_new].tolist()
+    assert ids_g == ids_e and taus_g == taus_e
+    assert replayed >= 8, replayed      # most steady-state cycles really went through the graphs
