@@ -430,6 +430,8 @@ def run_decode(model, target, input_ids: torch.Tensor, *, mask_token_id: int, ma
     decode_start = cuda_time()
     taus, used_bs, cycle_trace, lgens = [], [], [], []
     draft_prefill = True
+    use_graphs = os.environ.get("DFL_GRAPH", "0") == "1" and s.native and getattr(target, "attn_impl", "") == "head" \
+        and not getattr(target, "fuse_oproj", False)
     cyc = 0
     while s.start < s.max_length:
         cycle_t0 = cuda_time() if scheduler is not None else None
@@ -460,8 +462,17 @@ def run_decode(model, target, input_ids: torch.Tensor, *, mask_token_id: int, ma
         want_hidden = s.use_draft if (scheduler is not None or not clamp_tail) else bs > 1
         gen_before = s.start - s.n_in
         start_idx = s.start
-        r = s.cycle(bs, draft_steps=draft_steps, want_hidden=want_hidden, after_draft=after_draft,
-                    ahead_ok=scheduler is None and draft_steps == 1)
+        # DFL_GRAPH=1: fixed-size loops replay their steady-state cycles from two hipGraphs (DecodeSession.capture): the
+        # host's share of a cycle drops from ~2.3 ms to ~0.2 ms, the cycle itself is ~3 % longer
+        if (use_graphs and scheduler is None and draft_steps == 1 and not collect_profile and bs == block_size
+                and 2 <= bs <= 16 and want_hidden and not draft_prefill and s._ahead == bs and s.stop_t is None
+                and temperature < 1e-5 and draft_temperature < 1e-5):
+            if getattr(s, "_graph_bs", None) is None:
+                s.capture(bs)
+            r = s.cycle_graph(bs)
+        else:
+            r = s.cycle(bs, draft_steps=draft_steps, want_hidden=want_hidden, after_draft=after_draft,
+                        ahead_ok=scheduler is None and draft_steps == 1)
         taus.append(r.tau)
         used_bs.append(bs)
         lgens.append(lg[0])

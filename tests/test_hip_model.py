@@ -919,3 +919,32 @@ def test_graph_replayed_cycles_equal_eager_cycles():
     assert ids_e == G[:41 + n_new].tolist()
     assert ids_g == ids_e and taus_g == taus_e
     assert replayed >= 8, replayed      # most steady-state cycles really went through the graphs
+
+
+def test_generate_loop_with_graph_replay_env(monkeypatch):
+    """DFL_GRAPH=1: dflash_generate replays its steady-state cycles from the captured graphs — same ids, same acceptance
+    lengths as the eager loop (model/dflash.py:235-268 per cycle either way)."""
+    from dflash_amd import NativeTarget, dflash_generate
+    from dflash_amd.synthetic import greedy_walk, impose_greedy_walk
+    cfg = H.tiny_cfg()
+    hf = _tiny_hf()
+    perm = impose_greedy_walk(hf, seed=5)
+    prompt = torch.randint(0, 2000, (1, 33), generator=torch.Generator().manual_seed(4)).to(dev())
+    n_new = 120
+    G = greedy_walk(perm, prompt, n_new + 40).to(dev())
+    plan = H.make_plan(64, 16, 17)
+
+    def hook(blk, start, call):
+        k = min(plan[call], blk.shape[1] - 1)
+        blk[0, 1:k + 1] = G[start + 1:start + k + 1]
+        if k + 1 < blk.shape[1]:
+            blk[0, k + 1] = (G[start + k + 1] + 1) % 2000
+
+    runs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("DFL_GRAPH", mode)
+        r = dflash_generate(make_model(cfg), NativeTarget(hf), prompt, cfg.mask_token_id, n_new, 16, None, 0.0,
+                            draft_token_hook=hook)
+        assert r.output_ids[0].tolist() == G[:33 + n_new].tolist(), mode
+        runs[mode] = r
+    assert runs["0"].acceptance_lengths == runs["1"].acceptance_lengths
