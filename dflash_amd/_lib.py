@@ -64,6 +64,8 @@ SIGNATURES = {
                                 _p, _i, _p, _i64, _p, _p, _i64, _i, _p]),
     "dfl_attn_head_batch": (_i, [_p, _i64, _i, _i, _i, _i, _i64, _i, _i, _p, _p, _f, _p, _p, _i, _p, _p, _i, _i64, _f, _i,
                                  _p, _i, _p, _i, _p, _i64, _p]),
+    "dfl_attn_head_batch_t": (_i, [_p, _i64, _i, _i, _i, _i, _i64, _i, _i, _p, _p, _f, _p, _p, _i, _p, _p, _i, _i64, _f, _i,
+                                   _p, _i, _p, _i, _p, _i64, _i64, _i, _p]),
     "dfl_topk_rows": (_i, [_p, _i64, _i, _i, _i, _p, _p, _p, _p]),
     "dfl_candidate_select": (_i, [_p, _i64, _p, _i64, _p, _i, _i, _p, _i64, _p, _p, _i, _p, _p]),
     "dfl_moe_route": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p]),
@@ -102,10 +104,13 @@ SIGNATURES = {
     "dfl_norm_frag_batch": (_i, [_p, _i64, _i64, _i, _p, _i, _i64, _i, _p, _i64, _i64, _p, _f, _p, _i64, _i, _p, _i, _p]),
     "dfl_kv_append_batch": (_i, [_p, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i64, _f, _p, _p, _i, _p, _p, _i,
                                  _i64, _i64, _p, _p]),
+    "dfl_kv_append_batch_t": (_i, [_p, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i64, _f, _p, _p, _i, _p, _p, _i,
+                                   _i64, _i64, _p, _i, _p]),
     "dfl_attn_fused_batch_ws_bytes": (_i64, [_i, _i, _i, _i]),
     "dfl_attn_fused_batch": (_i, [_p, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _f, _p, _p, _i, _p, _p, _i,
                                   _i64, _f, _i, _p, _i, _p, _i, _p, _i64, _p]),
     "dfl_accept_commit_batch": (_i, [_p, _i64, _p, _i64, _i, _p, _i64, _i64, _p, _p, _p, _i, _p, _p, _i64, _p]),
+    "dfl_accept_commit_batch_t": (_i, [_p, _i64, _p, _i64, _i, _p, _i64, _i64, _p, _p, _p, _i, _p, _p, _i64, _i, _p, _p, _p]),
 }
 
 _lib = None

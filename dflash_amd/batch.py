@@ -51,18 +51,30 @@ class BatchedDecoder:
 
     def __init__(self, model: DFlashDraftModel, target: NativeTarget, n_requests: int, max_rows: int,
                  out_len: int, mask_token_id: int, stop_token_ids=None, max_splits: int = 32,
-                 temperature: float = 0.0):
+                 temperature: float = 0.0, tiles_per_request: int = 1):
         if not isinstance(target, NativeTarget):
             raise TypeError("BatchedDecoder needs a dflash_amd.NativeTarget (see module docstring)")
-        if not 1 <= n_requests <= MAX_GROUP:
-            raise ValueError(f"a group holds 1..{MAX_GROUP} requests")
+        if tiles_per_request not in (1, 2):
+            raise ValueError("tiles_per_request is 1 (blocks of <= 16 rows) or 2 (blocks of <= 32 rows)")
+        if not 1 <= n_requests * tiles_per_request <= MAX_GROUP:
+            raise ValueError(f"a group holds 1..{MAX_GROUP} sixteen-row tiles (requests x tiles_per_request)")
+        if tiles_per_request == 2 and temperature >= 1e-5:
+            raise NotImplementedError("blocks of more than 16 rows in the ragged batch are greedy (T = 0)")
         if model.w is None:
             raise RuntimeError("draft weights not loaded")
         c, t = model.config, target
         if c.hidden_size != t.H:
             raise ValueError("draft and target hidden sizes differ")
         self.model, self.target, self.cfg = model, target, c
-        self.R, self.MT = n_requests, ops.batch_tiles(n_requests)
+        # Blocks of 17..32 rows (benchmark.py's block-size sweep): a request takes TPR = 2 consecutive 16-row tiles of every
+        # per-tile launch (GEMMs, norms, embedding, context K/V append), one cache, one slot of the attention / accept
+        # launches.  Two kinds of length records then: per REQUEST (dyn_d / dyn_t: attention, accept) and per TILE (dyn_dt /
+        # dyn_tt: valid rows of each tile), both kept by dfl_accept_commit_batch_t.  TPR = 1: the same tensors.
+        self.TPR = TPR = tiles_per_request
+        self.R, self.NT = n_requests, n_requests * TPR
+        self.MT = ops.batch_tiles(self.NT)
+        self.BW = 16 * TPR                    # slots of a request's block
+        NREQ = self.MT // TPR                 # request slots of the caches / id buffers
         self.dev = dev = model.device
         self.max_rows, self.out_len, self.mask_id = int(max_rows), int(out_len), int(mask_token_id)
         self.max_splits = max_splits
@@ -73,15 +85,17 @@ class BatchedDecoder:
 
         # ---- lengths (device): draft form and block form, see dfl_accept_commit_batch
         self.dyn_d, self.dyn_t = z(MT, 8, dt=I32), z(MT, 8, dt=I32)
+        self.dyn_dt, self.dyn_tt = (self.dyn_d, self.dyn_t) if TPR == 1 else (z(MT, 8, dt=I32), z(MT, 8, dt=I32))
         # ---- caches [request][layer][kv head][row][128]
         Ld, Lt = c.num_hidden_layers, t.L
-        self.dk, self.dv = z(MT, Ld, c.num_key_value_heads, max_rows, 128), z(MT, Ld, c.num_key_value_heads, max_rows, 128)
-        self.tk, self.tv = z(MT, Lt, t.n_kv, max_rows, 128), z(MT, Lt, t.n_kv, max_rows, 128)
+        self.dk, self.dv = z(NREQ, Ld, c.num_key_value_heads, max_rows, 128), z(NREQ, Ld, c.num_key_value_heads, max_rows, 128)
+        self.tk, self.tv = z(NREQ, Lt, t.n_kv, max_rows, 128), z(NREQ, Lt, t.n_kv, max_rows, 128)
         # ---- ids
-        self.block = torch.full((MT, 16), self.mask_id, dtype=I64, device=dev)
-        self.post = z(MT, 16, dt=I64)
+        self.block = torch.full((NREQ, self.BW), self.mask_id, dtype=I64, device=dev)
+        self.post = z(NREQ, self.BW, dt=I64)
+        self.ids_tmp = z(MT, 16, dt=I64)      # TPR = 2: the draft's ids of every tile row (row 0 of tile 0 is not a draft token)
         self.result = z(MT, 4, dt=I32)
-        self.output_ids = torch.full((MT, out_len), self.mask_id, dtype=I64, device=dev)
+        self.output_ids = torch.full((NREQ, out_len), self.mask_id, dtype=I64, device=dev)
         self.stop_t = torch.tensor(stop_token_ids, dtype=I64, device=dev) if stop_token_ids else None
         # ---- draft scratch
         self.nqkv_d = c.q_dim + 2 * c.kv_dim
@@ -112,8 +126,10 @@ class BatchedDecoder:
         self.aws_t = ops.attn_fused_batch_ws(MT, t.n_q, t.n_kv, max_splits, dev)
         # round 2: the attention stage on finished bf16 q/k/v rows (dfl_attn_head_batch); "fused" keeps the round-1 stage
         self.attn_impl = getattr(model, "attn_impl", "head")
-        self.hws_d = ops.attn_head_batch_ws(MT, c.num_attention_heads, max_splits, dev)
-        self.hws_t = ops.attn_head_batch_ws(MT, t.n_q, max_splits, dev)
+        self.hws_d = ops.attn_head_batch_ws(MT, c.num_attention_heads, max_splits, dev, q_tiles=TPR)
+        self.hws_t = ops.attn_head_batch_ws(MT, t.n_q, max_splits, dev, q_tiles=TPR)
+        if TPR == 2 and self.attn_impl != "head":
+            raise NotImplementedError("blocks of more than 16 rows need the 'head' attention stage")
         self.d["xq"], self.t["xq"] = z(MT, 16, self.nqkv_d), z(MT, 16, t.nqkv)
         # ---- row sources
         # (normalised operands come from dfl_norm_frag_batch: at 4 tiles the in-GEMM norm of the
@@ -129,7 +145,7 @@ class BatchedDecoder:
         self.n_in = [0] * R
         self.live = [False] * R
         self.hook_calls = [0] * R
-        self.bs = [16] * R
+        self.bs = [self.BW] * R
         self.events = None  # set to a dict to have cycle() record (start, end) event pairs per phase
         self._ahead, self._ahead_ev = False, None   # a run-ahead draft is in flight (cycle(ahead_ok=True))
         self.run_ahead = os.environ.get("DFL_RUN_AHEAD", "1") != "0"
@@ -151,7 +167,7 @@ class BatchedDecoder:
         if input_ids.shape[0] != 1 or not input_ids.is_cuda:
             raise ValueError("admit: input_ids must be a [1, P] GPU tensor")
         P = input_ids.shape[1]
-        if P + 2 * 16 > self.max_rows or P + 1 > self.out_len:
+        if P + 2 * self.BW > self.max_rows or P + 1 > self.out_len:
             raise ValueError("admit: prompt does not fit the group's caches")
         if self.lm_wp is None:
             self.lm_wp = m.packed_lm_head(t.lm_head)
@@ -168,31 +184,42 @@ class BatchedDecoder:
         dc = _View(self.dk[r], self.dv[r], torch.zeros(8, dtype=I32, device=self.dev), self.max_rows)
         if P > n_tail:
             m.prefill_context(dc, th[:P - n_tail], 0)
-        self.d["taps"][r].zero_()
-        self.d["taps"][r, :n_tail] = th[P - n_tail:]
+        t0, BW = r * self.TPR, self.BW
+        self.d["taps"][t0:t0 + self.TPR].zero_()
+        self.d["taps"][t0, :n_tail] = th[P - n_tail:]      # (the tail rows fit the request's first tile)
         self.block[r].fill_(self.mask_id)
         self.block[r, 0:1] = first[0]
         S = P - n_tail
-        self.dyn_d[r] = torch.tensor([S, n_tail, 16, S, P, 0, 0, 0], dtype=I32)
-        self.dyn_t[r] = torch.tensor([P, 0, 16, P, P, 0, 0, 0], dtype=I32)
-        self.start[r], self.n_in[r], self.live[r], self.hook_calls[r], self.bs[r] = P, P, True, 0, 16
+        self.dyn_d[r] = torch.tensor([S, n_tail, BW, S, P, 0, 0, 0], dtype=I32)
+        self.dyn_t[r] = torch.tensor([P, 0, BW, P, P, 0, 0, 0], dtype=I32)
+        if self.TPR == 2:
+            for j in range(2):
+                self.dyn_dt[t0 + j] = torch.tensor([S + 16 * j, n_tail if j == 0 else 0, 0, S + 16 * j, P, 0, 0, 0], dtype=I32)
+                self.dyn_tt[t0 + j] = torch.tensor([P, 0, 16, P, P, 0, 0, 0], dtype=I32)
+        self.start[r], self.n_in[r], self.live[r], self.hook_calls[r], self.bs[r] = P, P, True, 0, BW
 
     def park(self, r: int) -> None:
         """Request r is finished: its tile stays in the launches but does no work."""
         self.live[r] = False
         self.dyn_d[r, ops.DYN_TAU:ops.DYN_BS + 1] = 0
         self.dyn_t[r, ops.DYN_BS] = 0
+        if self.TPR == 2:
+            self.dyn_dt[2 * r:2 * r + 2, ops.DYN_TAU:ops.DYN_BS + 1] = 0
+            self.dyn_tt[2 * r:2 * r + 2, ops.DYN_BS] = 0
 
     def set_block_size(self, r: int, bs: int) -> None:
         """Tail clamp (benchmark.py:104-105): a host write only when the size changes."""
         if bs != self.bs[r]:
             self.dyn_d[r, ops.DYN_BS] = bs
             self.dyn_t[r, ops.DYN_BS] = bs
+            if self.TPR == 2:
+                self.dyn_tt[2 * r, ops.DYN_BS] = min(bs, 16)
+                self.dyn_tt[2 * r + 1, ops.DYN_BS] = max(0, bs - 16)
             self.bs[r] = bs
 
     # ------------------------------------------------------------------ one cycle
     def _kv_len_max(self) -> int:
-        return max([self.start[r] for r in range(self.R) if self.live[r]] + [1]) + 16
+        return max([self.start[r] for r in range(self.R) if self.live[r]] + [1]) + self.BW
 
     def draft(self) -> None:
         """Draft forward + lm_head + greedy unmask for every live request
@@ -203,62 +230,71 @@ class BatchedDecoder:
         self._mark("lm_head", 1)
 
     def _draft_body(self, kvmax: int) -> None:
-        m, c, d, s, R, MT = self.model, self.cfg, self.d, self.src_d, self.R, self.MT
+        m, c, d, s, MT = self.model, self.cfg, self.d, self.src_d, self.MT
+        R, RQ, TPR = self.NT, self.R, self.TPR     # R: 16-row tiles of the per-tile launches; RQ: requests (attention)
+        dyn_d, dyn_t = self.dyn_dt, self.dyn_tt    # per-tile records (the per-request ones when TPR = 1)
         H, I = c.hidden_size, c.intermediate_size
         L = m.w["layers"]
         cos, sin = m._rope_tab(kvmax + 64)
-        ops.embed_rows_batch(self.embed_w, self.block, R, d["h"], H, d["ss_emb"], self.dyn_t, ops.DYN_BS)
+        ops.embed_rows_batch(self.embed_w, self.block.view(-1, 16), R, d["h"], H, d["ss_emb"], dyn_t, ops.DYN_BS)
         # context rows: fc, then K/V of all layers appended to the draft caches
         eps = c.rms_norm_eps
         ops.gemm_resid_batch(m.w["fc"], s["taps"], R, H, c.fc_in, d["ctxh"], add_residual=False, ws=self.gws,
-                             dyn=self.dyn_d)
-        ops.norm_frag_batch(d["ctxh"], R, m.w["hidden_norm"], eps, d["xn"], self.dyn_d, ops.DYN_TAU)
-        ops.gemm_f32_batch(self.kv_all, s["xn"], R, self.nkv_all, H, d["part_kv"], self.dyn_d)
+                             dyn=dyn_d)
+        ops.norm_frag_batch(d["ctxh"], R, m.w["hidden_norm"], eps, d["xn"], dyn_d, ops.DYN_TAU)
+        ops.gemm_f32_batch(self.kv_all, s["xn"], R, self.nkv_all, H, d["part_kv"], dyn_d)
         nsp = ops.batch_ksplit(H)
         ops.kv_append_batch(kv=d["part_kv"], nsplit=nsp, split_stride=MT * 16 * self.nkv_all, ld=self.nkv_all, k_col=0,
                             v_col=c.kv_dim, col_layer_stride=2 * c.kv_dim, n_layers=c.num_hidden_layers, R=R,
                             n_kv=c.num_key_value_heads, k_norm_w=self.k_norm_all, eps=c.rms_norm_eps, cos_tab=cos,
-                            sin_tab=sin, kcache=self.dk, vcache=self.dv, dyn=self.dyn_d)
+                            sin_tab=sin, kcache=self.dk, vcache=self.dv, dyn=dyn_d, tiles_per_req=TPR)
         # block rows.  o_proj / down_proj leave fp32 K-part sums; the residual add happens in the
         # norm launch that follows (the parts meet at the launch boundary, not inside the GEMM)
         pend = 0  # K of the GEMM whose sums are waiting in part_h (0: none)
         for i, lw in enumerate(L):
-            ops.norm_frag_batch(d["h"], R, lw["ln1"], eps, d["xn"], self.dyn_t, ops.DYN_BS,
+            ops.norm_frag_batch(d["h"], R, lw["ln1"], eps, d["xn"], dyn_t, ops.DYN_BS,
                                 part=d["part_h"] if pend else None, N=H, K=pend)
             if self.attn_impl == "head":
                 ops.gemm_resid_batch(lw["qkv"], s["xn"], R, self.nqkv_d, H, d["xq"], add_residual=False, ws=self.gws,
-                                     dyn=self.dyn_t)
-                ops.attn_head_batch(xq=d["xq"], q_col=0, k_col=c.q_dim, v_col=c.q_dim + c.kv_dim, R=R,
+                                     dyn=dyn_t)
+                ops.attn_head_batch(xq=d["xq"], q_col=0, k_col=c.q_dim, v_col=c.q_dim + c.kv_dim, R=RQ,
                                     n_q=c.num_attention_heads, n_kv=c.num_key_value_heads, q_norm_w=lw["q_norm"],
                                     k_norm_w=lw["k_norm"], eps=c.rms_norm_eps, cos_tab=cos, sin_tab=sin, kcache=self.dk,
                                     vcache=self.dv, layer=i, scale=c.head_dim ** -0.5, causal=False, dyn=self.dyn_t,
-                                    kv_len_max=kvmax, ws=self.hws_d, max_splits=self.max_splits, out_frag=d["attn"])
+                                    kv_len_max=kvmax, ws=self.hws_d, max_splits=self.max_splits, out_frag=d["attn"],
+                                    q_tiles=TPR)
             else:
-                ops.gemm_f32_batch(lw["qkv"], s["xn"], R, self.nqkv_d, H, d["part_qkv"], self.dyn_t)
+                ops.gemm_f32_batch(lw["qkv"], s["xn"], R, self.nqkv_d, H, d["part_qkv"], dyn_t)
                 ops.attn_fused_batch(qkv=d["part_qkv"], nsplit=nsp, split_stride=MT * 16 * self.nqkv_d, ld=self.nqkv_d,
                                      q_col=0, k_col=c.q_dim, v_col=c.q_dim + c.kv_dim, R=R, n_q=c.num_attention_heads,
                                      n_kv=c.num_key_value_heads, q_norm_w=lw["q_norm"], k_norm_w=lw["k_norm"],
                                      eps=c.rms_norm_eps, cos_tab=cos, sin_tab=sin, kcache=self.dk, vcache=self.dv,
-                                     layer=i, scale=c.head_dim ** -0.5, causal=False, dyn=self.dyn_t, kv_len_max=kvmax,
+                                     layer=i, scale=c.head_dim ** -0.5, causal=False, dyn=dyn_t, kv_len_max=kvmax,
                                      ws=self.aws_d, max_splits=self.max_splits, out_frag=d["attn"])
-            ops.gemm_f32_batch(lw["o"], s["attn"], R, H, c.q_dim, d["part_h"], self.dyn_t)
-            ops.norm_frag_batch(d["h"], R, lw["ln2"], eps, d["xn"], self.dyn_t, ops.DYN_BS, part=d["part_h"], N=H,
+            ops.gemm_f32_batch(lw["o"], s["attn"], R, H, c.q_dim, d["part_h"], dyn_t)
+            ops.norm_frag_batch(d["h"], R, lw["ln2"], eps, d["xn"], dyn_t, ops.DYN_BS, part=d["part_h"], N=H,
                                 K=c.q_dim)
-            ops.gemm_silu_mul_batch(lw["gu"], s["xn"], R, I, H, d["act"], self.gws, self.dyn_t)
-            ops.gemm_f32_batch(lw["down"], s["act"], R, H, I, d["part_h"], self.dyn_t)
+            ops.gemm_silu_mul_batch(lw["gu"], s["xn"], R, I, H, d["act"], self.gws, dyn_t)
+            ops.gemm_f32_batch(lw["down"], s["act"], R, H, I, d["part_h"], dyn_t)
             pend = I
 
     def _draft_head(self) -> None:
-        m, c, d, s, R = self.model, self.cfg, self.d, self.src_d, self.R
-        ops.norm_frag_batch(d["h"], R, m.w["norm"], c.rms_norm_eps, d["xn"], self.dyn_t, ops.DYN_BS,
+        m, c, d, s, R = self.model, self.cfg, self.d, self.src_d, self.NT
+        ops.norm_frag_batch(d["h"], R, m.w["norm"], c.rms_norm_eps, d["xn"], self.dyn_tt, ops.DYN_BS,
                             part=d["part_h"], N=c.hidden_size, K=c.intermediate_size)  # last down_proj + final norm
-        ops.gemm_argmax_batch(self.lm_wp, s["xn"], R, c.vocab_size, c.hidden_size, 1, 15, self.gws, self.block, 1,
-                              self.dyn_t, nrows_dyn_word=ops.DYN_BS)
+        if self.TPR == 1:
+            ops.gemm_argmax_batch(self.lm_wp, s["xn"], R, c.vocab_size, c.hidden_size, 1, 15, self.gws, self.block, 1,
+                                  self.dyn_tt, nrows_dyn_word=ops.DYN_BS)
+        else:   # row 0 of a request's SECOND tile is a draft row: all 16 rows of every tile, row 0 of the block dropped here
+            ops.gemm_argmax_batch(self.lm_wp, s["xn"], R, c.vocab_size, c.hidden_size, 0, 16, self.gws, self.ids_tmp, 0,
+                                  self.dyn_tt, nrows_dyn_word=ops.DYN_BS)
+            self.block[:, 1:].copy_(self.ids_tmp.view(-1, self.BW)[:, 1:])
 
     def verify(self, kvmax: Optional[int] = None) -> None:
         """Target verify of every live request's block (model/dflash.py:249-257, T = 0):
         post[r] <- the target's greedy tokens, taps[r] <- the tapped layers' hidden rows."""
-        t, tt, s, R, MT, H = self.target, self.t, self.src_t, self.R, self.MT, self.cfg.hidden_size
+        t, tt, s, R, MT, H = self.target, self.t, self.src_t, self.NT, self.MT, self.cfg.hidden_size
+        RQ, TPR, dyn_t = self.R, self.TPR, self.dyn_tt    # (R: tiles, RQ: requests, dyn_t: per-tile records, see _draft_body)
         kvmax = kvmax or self._kv_len_max()
         cos, sin = t._rope_tab(kvmax + 64)
         taps = self.d["taps"]
@@ -266,7 +302,7 @@ class BatchedDecoder:
         if max(tl) >= t.L - 1:
             raise NotImplementedError("tapping the last layer (post-norm state) is not supported")
         nsp = ops.batch_ksplit(H)
-        ops.embed_rows_batch(t.embed, self.block, R, tt["h"], H, tt["ss_emb"], self.dyn_t, ops.DYN_BS)
+        ops.embed_rows_batch(t.embed, self.block.view(-1, 16), R, tt["h"], H, tt["ss_emb"], dyn_t, ops.DYN_BS)
         pend, ptap, pdup = 0, None, ()  # K and tap view of the down_proj whose sums wait in part_h
         slots = {}   # tapped layer -> its slots in the tap rows (build_target_layer_ids repeats layers for
         for j, l in enumerate(tl):   # shallow targets: model/utils.py:16-25 concatenates the state twice)
@@ -278,35 +314,35 @@ class BatchedDecoder:
 
         self._pend_ns = None   # part count of the pending sums when they are expert shares, not K parts
         for i, lw in enumerate(t.layers):
-            ops.norm_frag_batch(tt["h"], R, lw["ln1"], t.eps, tt["xn"], self.dyn_t, ops.DYN_BS,
+            ops.norm_frag_batch(tt["h"], R, lw["ln1"], t.eps, tt["xn"], dyn_t, ops.DYN_BS,
                                 part=tt["part_h"] if pend else None, N=H, K=pend, tap=ptap, nsplit=self._pend_ns)
             spread(pdup)
             if self.attn_impl == "head":
                 ops.gemm_resid_batch(lw["qkv"], s["xn"], R, t.nqkv, H, tt["xq"], add_residual=False, ws=self.gws,
-                                     dyn=self.dyn_t)
-                ops.attn_head_batch(xq=tt["xq"], q_col=0, k_col=t.q_dim, v_col=t.q_dim + t.kv_dim, R=R, n_q=t.n_q,
+                                     dyn=dyn_t)
+                ops.attn_head_batch(xq=tt["xq"], q_col=0, k_col=t.q_dim, v_col=t.q_dim + t.kv_dim, R=RQ, n_q=t.n_q,
                                     n_kv=t.n_kv, q_norm_w=lw["q_norm"], k_norm_w=lw["k_norm"], eps=t.eps, cos_tab=cos,
                                     sin_tab=sin, kcache=self.tk, vcache=self.tv, layer=i, scale=128 ** -0.5, causal=True,
                                     dyn=self.dyn_t, kv_len_max=kvmax, ws=self.hws_t, max_splits=self.max_splits,
-                                    out_frag=tt["attn"])
+                                    out_frag=tt["attn"], q_tiles=TPR)
             else:
-                ops.gemm_f32_batch(lw["qkv"], s["xn"], R, t.nqkv, H, tt["part_qkv"], self.dyn_t)
+                ops.gemm_f32_batch(lw["qkv"], s["xn"], R, t.nqkv, H, tt["part_qkv"], dyn_t)
                 ops.attn_fused_batch(qkv=tt["part_qkv"], nsplit=nsp, split_stride=MT * 16 * t.nqkv, ld=t.nqkv, q_col=0,
                                      k_col=t.q_dim, v_col=t.q_dim + t.kv_dim, R=R, n_q=t.n_q, n_kv=t.n_kv,
                                      q_norm_w=lw["q_norm"], k_norm_w=lw["k_norm"], eps=t.eps, cos_tab=cos, sin_tab=sin,
                                      kcache=self.tk, vcache=self.tv, layer=i, scale=128 ** -0.5, causal=True,
-                                     dyn=self.dyn_t, kv_len_max=kvmax, ws=self.aws_t,
+                                     dyn=dyn_t, kv_len_max=kvmax, ws=self.aws_t,
                                      max_splits=self.max_splits, out_frag=tt["attn"])
-            ops.gemm_f32_batch(lw["o"], s["attn"], R, H, t.q_dim, tt["part_h"], self.dyn_t)
-            ops.norm_frag_batch(tt["h"], R, lw["ln2"], t.eps, tt["xn"], self.dyn_t, ops.DYN_BS, part=tt["part_h"],
+            ops.gemm_f32_batch(lw["o"], s["attn"], R, H, t.q_dim, tt["part_h"], dyn_t)
+            ops.norm_frag_batch(tt["h"], R, lw["ln2"], t.eps, tt["xn"], dyn_t, ops.DYN_BS, part=tt["part_h"],
                                 N=H, K=t.q_dim)
             pns = None
             if "gu_e" in lw:   # sparse-MoE layer (Qwen3MoeSparseMoeBlock): the requests share attention and projections
                 pns = self._moe_mlp(lw)   # above; routing and expert weights are per request
                 pend = 1
             else:
-                ops.gemm_silu_mul_batch(lw["gu"], s["xn"], R, t.I, H, tt["act"], self.gws, self.dyn_t)
-                ops.gemm_f32_batch(lw["down"], s["act"], R, H, t.I, tt["part_h"], self.dyn_t)
+                ops.gemm_silu_mul_batch(lw["gu"], s["xn"], R, t.I, H, tt["act"], self.gws, dyn_t)
+                ops.gemm_f32_batch(lw["down"], s["act"], R, H, t.I, tt["part_h"], dyn_t)
                 pend = t.I
             # the layer's output (a tapped layer's hidden rows, model/utils.py:16-25) exists once the
             # next norm launch has added these sums: it writes the tap
@@ -314,11 +350,11 @@ class BatchedDecoder:
             ptap = taps[:, :, sl[0] * H:(sl[0] + 1) * H] if sl else None
             pdup = [(sl[0], b) for b in sl[1:]]
             self._pend_ns = pns
-        ops.norm_frag_batch(tt["h"], R, t.norm, t.eps, tt["xn"], self.dyn_t, ops.DYN_BS, part=tt["part_h"], N=H, K=pend,
+        ops.norm_frag_batch(tt["h"], R, t.norm, t.eps, tt["xn"], dyn_t, ops.DYN_BS, part=tt["part_h"], N=H, K=pend,
                             tap=ptap, nsplit=self._pend_ns)
         spread(pdup)
         if self.temperature < 1e-5:
-            ops.gemm_argmax_batch(self.lm_wp, s["xn"], R, t.V, H, 0, 16, self.gws, self.post, 0, self.dyn_t,
+            ops.gemm_argmax_batch(self.lm_wp, s["xn"], R, t.V, H, 0, 16, self.gws, self.post.view(-1, 16), 0, dyn_t,
                                   nrows_dyn_word=ops.DYN_BS)
         else:
             # T > 0 (model/utils.py:30-34): the same GEMM materialises the bf16 logits and the
@@ -326,17 +362,18 @@ class BatchedDecoder:
             # one draw over all requests' rows, so the stream differs from R sequential runs)
             if self._logits is None:
                 self._logits = torch.zeros(MT, 16, t.V, dtype=BF16, device=self.dev)
-            ops.gemm_argmax_batch(self.lm_wp, s["xn"], R, t.V, H, 0, 16, self.gws, self.post, 0, self.dyn_t,
+            ops.gemm_argmax_batch(self.lm_wp, s["xn"], R, t.V, H, 0, 16, self.gws, self.post, 0, dyn_t,
                                   nrows_dyn_word=ops.DYN_BS, logits=self._logits)
             self.post[:R] = sample(self._logits[:R], self.temperature)
 
     def _moe_mlp(self, lw: dict) -> int:
         """Sparse-MoE MLP of one target layer for the requests of the group: NativeTarget.moe_mlp_tiles."""
-        return self.target.moe_mlp_tiles(lw, self.R, self.MT, self.dyn_t, self.t["xn"], self.t["part_h"])
+        return self.target.moe_mlp_tiles(lw, self.NT, self.MT, self.dyn_tt, self.t["xn"], self.t["part_h"])
 
     def _accept_launch(self) -> None:
         ops.accept_commit_batch(self.block, self.post, self.R, self.output_ids, self.dyn_d, self.dyn_t, self.stop_t,
-                                self.result, rearm_mask_id=self.mask_id)
+                                self.result, rearm_mask_id=self.mask_id, tiles_per_req=self.TPR,
+                                dyn_d_tiles=self.dyn_dt, dyn_t_tiles=self.dyn_tt)
 
     def accept(self, launch: bool = True) -> list:
         """Acceptance scan + commit + rollback bookkeeping of all requests (:258-268) and
@@ -429,7 +466,7 @@ class BatchedDecoder:
         if self.events is not None:
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             ev[0].record()
-        self._draft_body(self._kv_len_max() + 16)   # (the new starts are at most 16 rows further)
+        self._draft_body(self._kv_len_max() + self.BW)   # (the new starts are at most a block further)
         if ev:
             ev[2].record()
         self._draft_head()
@@ -446,11 +483,13 @@ def dflash_generate_batch(model: DFlashDraftModel, target: NativeTarget, input_i
                           temperature: float = 0.0, draft_token_hook: Optional[Callable] = None,
                           group_size: int = MAX_GROUP) -> list:
     """`dflash_generate` (benchmark.py:44-251) for a list of prompts: requests run in
-    groups of `group_size` <= 4 that share the weight stream; returns one namespace per
+    groups of `group_size` <= 4 (<= 2 with block sizes of 17..32 rows) that share the weight stream; returns one namespace per
     prompt with the fields of benchmark.py:242-251 (timing fields are the group's).
     draft_token_hook(request_index, block, start, call)."""
-    if block_size != 16:
-        raise NotImplementedError("the batched kernels take 16-row blocks")
+    if not 16 <= block_size <= 32:
+        raise NotImplementedError("the batched loop takes blocks of 16 rows (one tile per request) or 17..32 rows (two)")
+    tpr = 1 if block_size == 16 else 2      # blocks of 17..32 rows: a request takes two of the group's four tiles
+    group_size = min(group_size, MAX_GROUP // tpr)
     n = len(input_ids)
     results = [None] * n
     for g0 in range(0, n, group_size):
@@ -458,9 +497,9 @@ def dflash_generate_batch(model: DFlashDraftModel, target: NativeTarget, input_i
         prompts = [input_ids[i] for i in idx]
         pmax = max(p.shape[1] for p in prompts)
         max_len = [p.shape[1] + max_new_tokens for p in prompts]
-        dec = BatchedDecoder(model, target, len(idx), max_rows=pmax + max_new_tokens + 3 * 16,
-                             out_len=pmax + max_new_tokens + 16, mask_token_id=mask_token_id,
-                             stop_token_ids=stop_token_ids, temperature=temperature)
+        dec = BatchedDecoder(model, target, len(idx), max_rows=pmax + max_new_tokens + 3 * 16 * tpr,
+                             out_len=pmax + max_new_tokens + 16 * tpr, mask_token_id=mask_token_id,
+                             stop_token_ids=stop_token_ids, temperature=temperature, tiles_per_request=tpr)
         t0 = cuda_time()
         for r, p in enumerate(prompts):
             dec.admit(r, p, temperature)

@@ -126,7 +126,8 @@ __global__ __launch_bounds__(64) void k_accept_commit_b(const int64_t *block_ids
                                                         int64_t *output_ids, int64_t out_stride, int64_t output_len,
                                                         int32_t *dyn_d, int32_t *dyn_t, const int64_t *stop_ids,
                                                         int n_stop, int32_t *result, int64_t *next_block,
-                                                        int64_t mask_id) {
+                                                        int64_t mask_id, int rearm_n, int tiles_per_req, int32_t *dyn_dt,
+                                                        int32_t *dyn_tt) {
   const int r = blockIdx.x, i = threadIdx.x;
   if (next_block) next_block += r * blk_stride;
   block_ids += r * blk_stride;
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(64) void k_accept_commit_b(const int64_t *block_ids
   // the next cycle's block = output_ids[new start .. +bs) = [bonus token, mask, mask, ...]
   // (model/dflash.py:235); all reads of block_ids above precede these writes in the wave
   const int64_t bonus = __shfl(tok, acc + 1, 64);  // posterior[acc]; every lane takes part
-  if (next_block && bs > 0 && i < 16) next_block[i] = i == 0 ? bonus : mask_id;
+  if (next_block && bs > 0 && i < rearm_n) next_block[i] = i == 0 ? bonus : mask_id;
   if (i == 0 && bs > 0) {
     const int new_start = start + acc + 1;
     const int stop = dyn_d[DFL_DYN_STOP] | (any_stop ? 1 : 0);
@@ -171,6 +172,21 @@ __global__ __launch_bounds__(64) void k_accept_commit_b(const int64_t *block_ids
     dyn_t[DFL_DYN_START] = new_start;
     dyn_t[DFL_DYN_STOP] = stop;
     dyn_t[DFL_DYN_CYCLE] = cyc;
+    // blocks of 17..32 rows: the request's tiles have length records of their own for the per-tile launches (GEMMs,
+    // norms, context K/V append): tile j holds context rows 16 j .. of the tau accepted ones and block rows 16 j ..
+    for (int j = 0; dyn_dt && j < tiles_per_req; ++j) {
+      int32_t *dd = dyn_dt + (r * tiles_per_req + j) * DFL_DYN_WORDS, *dt = dyn_tt + (r * tiles_per_req + j) * DFL_DYN_WORDS;
+      const int tj = acc + 1 - 16 * j, bj = bs - 16 * j;
+      dd[DFL_DYN_S] = start + 16 * j;
+      dd[DFL_DYN_TAU] = tj < 0 ? 0 : (tj > 16 ? 16 : tj);
+      dd[DFL_DYN_POS0] = start + 16 * j;
+      dd[DFL_DYN_START] = new_start;
+      dt[DFL_DYN_S] = new_start;
+      dt[DFL_DYN_TAU] = 0;
+      dt[DFL_DYN_BS] = bj < 0 ? 0 : (bj > 16 ? 16 : bj);
+      dt[DFL_DYN_POS0] = new_start;
+      dt[DFL_DYN_START] = new_start;
+    }
     if (result) {
       result[r * 4 + 0] = acc;
       result[r * 4 + 1] = new_start;
@@ -245,7 +261,24 @@ extern "C" int dfl_accept_commit_batch(const int64_t *block_ids, int64_t blk_str
   DFL_REQUIRE(n_stop == 0 || stop_ids, "dfl_accept_commit_batch: n_stop>0 without stop_ids");
   hipLaunchKernelGGL(k_accept_commit_b, dim3(R), dim3(64), 0, (hipStream_t)stream, block_ids, blk_stride, posterior,
                      post_stride, output_ids, out_stride, output_len, dyn_d, dyn_t, stop_ids, n_stop, result, next_block,
-                     mask_id);
+                     mask_id, 16, 1, (int32_t *)nullptr, (int32_t *)nullptr);
   DFL_CHECK_LAUNCH("dfl_accept_commit_batch");
+  return DFL_OK;
+}
+
+extern "C" int dfl_accept_commit_batch_t(const int64_t *block_ids, int64_t blk_stride, const int64_t *posterior,
+                                         int64_t post_stride, int R, int64_t *output_ids, int64_t out_stride,
+                                         int64_t output_len, int32_t *dyn_d, int32_t *dyn_t, const int64_t *stop_ids,
+                                         int n_stop, int32_t *result, int64_t *next_block, int64_t mask_id, int tiles_per_req,
+                                         int32_t *dyn_d_tiles, int32_t *dyn_t_tiles, void *stream) {
+  DFL_REQUIRE(block_ids && posterior && output_ids && dyn_d && dyn_t && dyn_d_tiles && dyn_t_tiles,
+              "dfl_accept_commit_batch_t: null pointer");
+  DFL_REQUIRE(R >= 1 && R <= 1024 && (tiles_per_req == 1 || tiles_per_req == 2) && blk_stride >= 16 * tiles_per_req,
+              "dfl_accept_commit_batch_t: R=%d tiles_per_req=%d outside range", R, tiles_per_req);
+  DFL_REQUIRE(n_stop == 0 || stop_ids, "dfl_accept_commit_batch_t: n_stop>0 without stop_ids");
+  hipLaunchKernelGGL(k_accept_commit_b, dim3(R), dim3(64), 0, (hipStream_t)stream, block_ids, blk_stride, posterior,
+                     post_stride, output_ids, out_stride, output_len, dyn_d, dyn_t, stop_ids, n_stop, result, next_block,
+                     mask_id, 16 * tiles_per_req, tiles_per_req, dyn_d_tiles, dyn_t_tiles);
+  DFL_CHECK_LAUNCH("dfl_accept_commit_batch_t");
   return DFL_OK;
 }

@@ -1068,3 +1068,21 @@ extern "C" int dfl_attn_head_batch(const void *xq, int64_t ldq, int q_col, int k
                           out_frag, 0, R, xq_req_stride, out_req_stride, nullptr, nullptr, 0, 0, DFL_DYN_WORDS, cache_req_stride,
                           stream);
 }
+
+// Blocks of 17..32 rows in the ragged batch: request r = TWO consecutive 16-row tiles of xq / out_frag (strides per
+// request), one cache, one length record (bs = 17..32 counts both tiles).
+extern "C" int dfl_attn_head_batch_t(const void *xq, int64_t ldq, int q_col, int k_col, int v_col, int R, int64_t xq_req_stride,
+                                     int n_q, int n_kv, const void *q_norm_w, const void *k_norm_w, float eps,
+                                     const void *cos_tab, const void *sin_tab, int max_pos, void *kcache, void *vcache,
+                                     int cache_rows, int64_t cache_req_stride, float scale, int causal, const int32_t *dyn,
+                                     int kv_len_max, void *ws, int max_splits, void *out_frag, int64_t out_req_stride,
+                                     int64_t out_tile_stride, int q_tiles, void *stream) {
+  DFL_REQUIRE(dyn, "dfl_attn_head_batch_t: the requests' lengths come from dyn (R records)");
+  DFL_REQUIRE(q_tiles == 1 || q_tiles == 2, "dfl_attn_head_batch_t: q_tiles must be 1 or 2");
+  DFL_REQUIRE(kv_len_max >= 16 * q_tiles && kv_len_max <= cache_rows, "dfl_attn_head_batch_t: kv_len_max=%d outside range", kv_len_max);
+  return attn_head_launch(xq, ldq, q_col, k_col, v_col, nullptr, 0, 0, 0, n_q, n_kv, q_norm_w, k_norm_w, eps, cos_tab, sin_tab,
+                          max_pos, kcache, vcache, cache_rows, scale, causal, dyn, kv_len_max - 16 * q_tiles, 0, 16 * q_tiles, 0,
+                          q_tiles, ws, max_splits, out_frag, out_tile_stride, R, xq_req_stride, out_req_stride, nullptr, nullptr, 0,
+                          0, DFL_DYN_WORDS, cache_req_stride, stream);
+}
+

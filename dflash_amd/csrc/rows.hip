@@ -170,6 +170,7 @@ struct RopeArgs {
   int req_rows;
   int64_t cache_req_stride, cache_layer_stride, kw_layer_stride;
   int col_layer_stride;
+  int tiles_per_req;  // grid.y counts 16-row TILES; tiles_per_req consecutive ones belong to one request (one cache)
 };
 
 // One wave per (kind, row, head) item of 128 values; lane owns d = l and l + 64,
@@ -183,8 +184,9 @@ __global__ __launch_bounds__(256) void k_qknorm_rope(RopeArgs a_in) {
     a.dyn += r * DFL_DYN_WORDS;
     a.ctx_row0 += r * a.req_rows;
     if (a.blk_row0 >= 0) a.blk_row0 += r * a.req_rows;
-    a.kcache += r * a.cache_req_stride + ly * a.cache_layer_stride;
-    a.vcache += r * a.cache_req_stride + ly * a.cache_layer_stride;
+    const int rq = a.tiles_per_req > 1 ? r / a.tiles_per_req : r;
+    a.kcache += rq * a.cache_req_stride + ly * a.cache_layer_stride;
+    a.vcache += rq * a.cache_req_stride + ly * a.cache_layer_stride;
     a.k_col += ly * a.col_layer_stride;
     a.v_col += ly * a.col_layer_stride;
     if (a.k_w) a.k_w += ly * a.kw_layer_stride;
@@ -349,22 +351,44 @@ extern "C" int dfl_qknorm_rope_append(const float *qkv, int nsplit, int64_t spli
 }
 
 /* see include/dflash_hip.h */
+static int kv_append_batch_impl(const float *kv, int nsplit, int64_t split_stride, int ld, int k_col, int v_col,
+                                   int col_layer_stride, int n_layers, int R, int req_rows, int n_kv,
+                                   const void *k_norm_w, int64_t kw_layer_stride, float eps, const void *cos_tab,
+                                   const void *sin_tab, int max_pos, void *kcache, void *vcache, int cache_rows,
+                                   int64_t cache_req_stride, int64_t cache_layer_stride, const int32_t *dyn,
+                                   int tiles_per_req, void *stream) {
+  DFL_REQUIRE(kv && cos_tab && sin_tab && kcache && vcache && dyn, "dfl_kv_append_batch: null pointer");
+  DFL_REQUIRE(nsplit >= 1 && n_kv > 0 && ld > 0 && k_col >= 0 && v_col >= 0 && max_pos > 0, "dfl_kv_append_batch: bad layout");
+  DFL_REQUIRE(R >= 1 && R <= 64 && n_layers >= 1 && req_rows >= 16 && tiles_per_req >= 1, "dfl_kv_append_batch: bad batch shape");
+  RopeArgs a{kv, nsplit, split_stride, ld, -1, k_col, v_col, 0, -1, /*n_q=*/0, n_kv,
+             nullptr, (const bf16_t *)k_norm_w, eps, (const bf16_t *)cos_tab, (const bf16_t *)sin_tab,
+             max_pos, nullptr, (bf16_t *)kcache, (bf16_t *)vcache, cache_rows, dyn, -1, 0,
+             req_rows, cache_req_stride, cache_layer_stride, kw_layer_stride, col_layer_stride, tiles_per_req};
+  // no q items (n_q = 0); of the 32 k / v slots per head only the context ones (< tau) do work
+  const int items = 2 * 32 * n_kv;
+  hipLaunchKernelGGL(k_qknorm_rope, dim3((items + 3) / 4, R, n_layers), dim3(256), 0, (hipStream_t)stream, a);
+  DFL_CHECK_LAUNCH("dfl_kv_append_batch");
+  return DFL_OK;
+}
+
 extern "C" int dfl_kv_append_batch(const float *kv, int nsplit, int64_t split_stride, int ld, int k_col, int v_col,
                                    int col_layer_stride, int n_layers, int R, int req_rows, int n_kv,
                                    const void *k_norm_w, int64_t kw_layer_stride, float eps, const void *cos_tab,
                                    const void *sin_tab, int max_pos, void *kcache, void *vcache, int cache_rows,
                                    int64_t cache_req_stride, int64_t cache_layer_stride, const int32_t *dyn,
                                    void *stream) {
-  DFL_REQUIRE(kv && cos_tab && sin_tab && kcache && vcache && dyn, "dfl_kv_append_batch: null pointer");
-  DFL_REQUIRE(nsplit >= 1 && n_kv > 0 && ld > 0 && k_col >= 0 && v_col >= 0 && max_pos > 0, "dfl_kv_append_batch: bad layout");
-  DFL_REQUIRE(R >= 1 && R <= 64 && n_layers >= 1 && req_rows >= 16, "dfl_kv_append_batch: bad batch shape");
-  RopeArgs a{kv, nsplit, split_stride, ld, -1, k_col, v_col, 0, -1, /*n_q=*/0, n_kv,
-             nullptr, (const bf16_t *)k_norm_w, eps, (const bf16_t *)cos_tab, (const bf16_t *)sin_tab,
-             max_pos, nullptr, (bf16_t *)kcache, (bf16_t *)vcache, cache_rows, dyn, -1, 0,
-             req_rows, cache_req_stride, cache_layer_stride, kw_layer_stride, col_layer_stride};
-  // no q items (n_q = 0); of the 32 k / v slots per head only the context ones (< tau) do work
-  const int items = 2 * 32 * n_kv;
-  hipLaunchKernelGGL(k_qknorm_rope, dim3((items + 3) / 4, R, n_layers), dim3(256), 0, (hipStream_t)stream, a);
-  DFL_CHECK_LAUNCH("dfl_kv_append_batch");
-  return DFL_OK;
+  return kv_append_batch_impl(kv, nsplit, split_stride, ld, k_col, v_col, col_layer_stride, n_layers, R, req_rows, n_kv, k_norm_w,
+                              kw_layer_stride, eps, cos_tab, sin_tab, max_pos, kcache, vcache, cache_rows, cache_req_stride,
+                              cache_layer_stride, dyn, 1, stream);
+}
+
+extern "C" int dfl_kv_append_batch_t(const float *kv, int nsplit, int64_t split_stride, int ld, int k_col, int v_col,
+                                     int col_layer_stride, int n_layers, int n_tiles, int req_rows, int n_kv,
+                                     const void *k_norm_w, int64_t kw_layer_stride, float eps, const void *cos_tab,
+                                     const void *sin_tab, int max_pos, void *kcache, void *vcache, int cache_rows,
+                                     int64_t cache_req_stride, int64_t cache_layer_stride, const int32_t *dyn_tiles,
+                                     int tiles_per_req, void *stream) {
+  return kv_append_batch_impl(kv, nsplit, split_stride, ld, k_col, v_col, col_layer_stride, n_layers, n_tiles, req_rows, n_kv,
+                              k_norm_w, kw_layer_stride, eps, cos_tab, sin_tab, max_pos, kcache, vcache, cache_rows,
+                              cache_req_stride, cache_layer_stride, dyn_tiles, tiles_per_req, stream);
 }

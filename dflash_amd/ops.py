@@ -333,18 +333,28 @@ def attn_head_cand(*, xq: torch.Tensor, q_col: int, k_col: int, v_col: int, n_q:
         "dfl_attn_head_cand")
 
 
-def attn_head_batch_ws(R: int, n_q: int, max_splits: int, device) -> torch.Tensor:
-    return torch.zeros(R * lib().dfl_attn_head_ws_bytes(n_q, max_splits, 1), dtype=torch.uint8, device=device)
+def attn_head_batch_ws(R: int, n_q: int, max_splits: int, device, q_tiles: int = 1) -> torch.Tensor:
+    return torch.zeros(R * lib().dfl_attn_head_ws_bytes(n_q, max_splits, q_tiles), dtype=torch.uint8, device=device)
 
 
 def attn_head_batch(*, xq: torch.Tensor, q_col: int, k_col: int, v_col: int, R: int, n_q: int, n_kv: int, q_norm_w,
                     k_norm_w, eps, cos_tab, sin_tab, kcache, vcache, layer: int, scale: float, causal: bool, dyn,
-                    kv_len_max: int, ws, max_splits: int, out_frag: torch.Tensor) -> None:
-    """xq [MT, 16, ldq] bf16; kcache/vcache [MT, L, n_kv, rows, 128] (layer `layer` is used); out_frag [MT, 16*n_q*128]."""
+                    kv_len_max: int, ws, max_splits: int, out_frag: torch.Tensor, q_tiles: int = 1) -> None:
+    """xq [MT, 16, ldq] bf16; kcache/vcache [requests, L, n_kv, rows, 128] (layer `layer` is used); out_frag
+    [MT, 16*n_q*128].  q_tiles = 2: request r owns tiles 2 r, 2 r + 1 of xq / out_frag (blocks of 17..32 rows), dyn holds
+    one record per REQUEST."""
     assert xq.is_cuda and xq.dtype == BF16 and xq.dim() == 3 and xq.stride(2) == 1
     assert kcache.shape == vcache.shape and kcache.dim() == 5 and kcache.shape[4] == 128 and kcache.is_contiguous()
     assert out_frag.dim() == 2 and out_frag.is_contiguous()
     kc, vc = kcache[0, layer], vcache[0, layer]
+    if q_tiles != 1:
+        check(lib().dfl_attn_head_batch_t(
+            xq.data_ptr(), xq.stride(1), q_col, k_col, v_col, R, q_tiles * xq.stride(0), n_q, n_kv,
+            _p(q_norm_w, BF16, "q_norm_w"), _p(k_norm_w, BF16, "k_norm_w"), eps, _p(cos_tab, BF16, "cos"),
+            _p(sin_tab, BF16, "sin"), cos_tab.shape[0], kc.data_ptr(), vc.data_ptr(), kcache.shape[3], kcache.stride(0), scale,
+            int(causal), _p(dyn, I32, "dyn"), kv_len_max, _p(ws), max_splits, _p(out_frag, BF16, "out_frag"),
+            q_tiles * out_frag.stride(0), out_frag.stride(0), q_tiles, _stream()), "dfl_attn_head_batch_t")
+        return
     check(lib().dfl_attn_head_batch(
         xq.data_ptr(), xq.stride(1), q_col, k_col, v_col, R, xq.stride(0), n_q, n_kv, _p(q_norm_w, BF16, "q_norm_w"),
         _p(k_norm_w, BF16, "k_norm_w"), eps, _p(cos_tab, BF16, "cos"), _p(sin_tab, BF16, "sin"), cos_tab.shape[0],
@@ -588,7 +598,7 @@ def norm_frag_batch(h: torch.Tensor, R: int, norm_w: torch.Tensor, eps: float, f
 
 
 def kv_append_batch(*, kv, nsplit, split_stride, ld, k_col, v_col, col_layer_stride, n_layers, R, n_kv, k_norm_w,
-                    eps, cos_tab, sin_tab, kcache, vcache, dyn) -> None:
+                    eps, cos_tab, sin_tab, kcache, vcache, dyn, tiles_per_req: int = 1) -> None:
     """kcache/vcache [MT, L, n_kv, rows, 128]; k_norm_w [L, 128] or None.  A 4-D cache [L, n_kv, rows, 128] is ONE
     request's cache shared by all R tiles (request stride 0): the tiles are then consecutive 16-row groups of that
     request's context rows (the large-M context prefill), each with its own S / pos0 in its dyn record."""
@@ -598,6 +608,13 @@ def kv_append_batch(*, kv, nsplit, split_stride, ld, k_col, v_col, col_layer_str
     else:
         assert kcache.dim() == 5
         rows, req_stride, layer_stride = kcache.shape[3], kcache.stride(0), kcache.stride(1)
+    if tiles_per_req != 1:    # R counts tiles, dyn holds one record per tile, tiles_per_req tiles share a request's cache
+        check(lib().dfl_kv_append_batch_t(
+            _p(kv, F32, "kv"), nsplit, split_stride, ld, k_col, v_col, col_layer_stride, n_layers, R, 16, n_kv,
+            _p(k_norm_w, BF16, "k_norm_w"), 128, eps, _p(cos_tab, BF16, "cos"), _p(sin_tab, BF16, "sin"),
+            cos_tab.shape[0], _p(kcache, BF16, "kcache"), _p(vcache, BF16, "vcache"), rows,
+            req_stride, layer_stride, _p(dyn, I32, "dyn"), tiles_per_req, _stream()), "dfl_kv_append_batch_t")
+        return
     check(lib().dfl_kv_append_batch(
         _p(kv, F32, "kv"), nsplit, split_stride, ld, k_col, v_col, col_layer_stride, n_layers, R, 16, n_kv,
         _p(k_norm_w, BF16, "k_norm_w"), 128, eps, _p(cos_tab, BF16, "cos"), _p(sin_tab, BF16, "sin"),
@@ -626,10 +643,21 @@ def attn_fused_batch(*, qkv, nsplit, split_stride, ld, q_col, k_col, v_col, R, n
 
 
 def accept_commit_batch(block: torch.Tensor, posterior: torch.Tensor, R: int, output_ids: torch.Tensor, dyn_d, dyn_t,
-                        stop_ids, result: torch.Tensor, rearm_mask_id: Optional[int] = None) -> None:
-    """block/posterior int64 [MT, 16]; output_ids int64 [MT, n]; result int32 [MT, 4]."""
+                        stop_ids, result: torch.Tensor, rearm_mask_id: Optional[int] = None, tiles_per_req: int = 1,
+                        dyn_d_tiles=None, dyn_t_tiles=None) -> None:
+    """block/posterior int64 [requests, 16 * tiles_per_req]; output_ids int64 [requests, n]; result int32 [requests, 4];
+    tiles_per_req = 2: the per-tile records dyn_d_tiles / dyn_t_tiles are kept as well (dfl_accept_commit_batch_t)."""
     assert block.dim() == 2 and posterior.dim() == 2 and output_ids.dim() == 2
     n_stop = 0 if stop_ids is None else stop_ids.numel()
+    if tiles_per_req != 1:
+        check(lib().dfl_accept_commit_batch_t(
+            _p(block, I64, "block"), block.stride(0), _p(posterior, I64, "posterior"), posterior.stride(0), R,
+            _p(output_ids, I64, "output_ids"), output_ids.stride(0), output_ids.shape[1], _p(dyn_d, I32, "dyn_d"),
+            _p(dyn_t, I32, "dyn_t"), _p(stop_ids, I64, "stop_ids") if n_stop else None, n_stop,
+            _p(result, I32, "result"), block.data_ptr() if rearm_mask_id is not None else None,
+            int(rearm_mask_id) if rearm_mask_id is not None else 0, tiles_per_req, _p(dyn_d_tiles, I32, "dyn_d_tiles"),
+            _p(dyn_t_tiles, I32, "dyn_t_tiles"), _stream()), "dfl_accept_commit_batch_t")
+        return
     check(lib().dfl_accept_commit_batch(
         _p(block, I64, "block"), block.stride(0), _p(posterior, I64, "posterior"), posterior.stride(0), R,
         _p(output_ids, I64, "output_ids"), output_ids.stride(0), output_ids.shape[1], _p(dyn_d, I32, "dyn_d"),

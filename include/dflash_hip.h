@@ -274,6 +274,15 @@ int dfl_attn_head_batch(const void *xq, int64_t ldq, int q_col, int k_col, int v
                         const void *sin_tab, int max_pos, void *kcache, void *vcache, int cache_rows,
                         int64_t cache_req_stride, float scale, int causal, const int32_t *dyn, int kv_len_max, void *ws,
                         int max_splits, void *out_frag, int64_t out_req_stride, void *stream);
+/* The same for blocks of 17..32 rows (q_tiles = 2; benchmark.py's block-size sweep, results.md:11-16, with several requests
+ * per GPU): request r is TWO consecutive 16-row tiles of xq and of out_frag (out_tile_stride elements apart), one cache and
+ * one length record whose bs counts both tiles.  ws: R * dfl_attn_head_ws_bytes(n_q, max_splits, q_tiles) bytes. */
+int dfl_attn_head_batch_t(const void *xq, int64_t ldq, int q_col, int k_col, int v_col, int R, int64_t xq_req_stride, int n_q,
+                          int n_kv, const void *q_norm_w, const void *k_norm_w, float eps, const void *cos_tab,
+                          const void *sin_tab, int max_pos, void *kcache, void *vcache, int cache_rows,
+                          int64_t cache_req_stride, float scale, int causal, const int32_t *dyn, int kv_len_max, void *ws,
+                          int max_splits, void *out_frag, int64_t out_req_stride, int64_t out_tile_stride, int q_tiles,
+                          void *stream);
 
 /* Per row of bf16 logits [rows][ld] (rows <= 64): the k <= 8 largest values with their indices, ordered (value
  * descending, index ascending) — out_val fp32 [rows][8], out_idx int32 [rows][8] — and the row's log-sum-exp (fp32).
@@ -505,6 +514,13 @@ int dfl_kv_append_batch(const float *kv, int nsplit, int64_t split_stride, int l
                         int64_t kw_layer_stride, float eps, const void *cos_tab, const void *sin_tab, int max_pos,
                         void *kcache, void *vcache, int cache_rows, int64_t cache_req_stride,
                         int64_t cache_layer_stride, const int32_t *dyn, void *stream);
+/* The same over n_tiles 16-row TILES with one length record each (dyn_tiles), tiles_per_req consecutive tiles sharing one
+ * request's cache: the context rows of requests that run 17..32-row blocks (up to 32 accepted rows per cycle). */
+int dfl_kv_append_batch_t(const float *kv, int nsplit, int64_t split_stride, int ld, int k_col, int v_col,
+                          int col_layer_stride, int n_layers, int n_tiles, int req_rows, int n_kv, const void *k_norm_w,
+                          int64_t kw_layer_stride, float eps, const void *cos_tab, const void *sin_tab, int max_pos,
+                          void *kcache, void *vcache, int cache_rows, int64_t cache_req_stride,
+                          int64_t cache_layer_stride, const int32_t *dyn_tiles, int tiles_per_req, void *stream);
 
 /* dfl_attn_fused for R requests (grid.z = request): request r's block rows at partial-buffer
  * rows blk_row0 + r * req_rows, cache at + r * cache_req_stride, frag16 output at
@@ -529,6 +545,15 @@ int dfl_accept_commit_batch(const int64_t *block_ids, int64_t blk_stride, const 
                             int64_t post_stride, int R, int64_t *output_ids, int64_t out_stride, int64_t output_len,
                             int32_t *dyn_d, int32_t *dyn_t, const int64_t *stop_ids, int n_stop, int32_t *result,
                             int64_t *next_block, int64_t mask_id, void *stream);
+/* The same for requests of tiles_per_req (1 or 2) 16-row tiles — blocks of up to 32 rows: besides the per-request records
+ * it keeps one record per TILE for the per-tile launches (dyn_d_tiles: S / pos0 = start + 16 j, tau = the tile's share of
+ * the acc + 1 context rows; dyn_t_tiles: block form with bs = the tile's share of the block rows); the re-armed block has
+ * 16 * tiles_per_req slots. */
+int dfl_accept_commit_batch_t(const int64_t *block_ids, int64_t blk_stride, const int64_t *posterior,
+                              int64_t post_stride, int R, int64_t *output_ids, int64_t out_stride, int64_t output_len,
+                              int32_t *dyn_d, int32_t *dyn_t, const int64_t *stop_ids, int n_stop, int32_t *result,
+                              int64_t *next_block, int64_t mask_id, int tiles_per_req, int32_t *dyn_d_tiles,
+                              int32_t *dyn_t_tiles, void *stream);
 
 #ifdef __cplusplus
 }

@@ -519,3 +519,40 @@ def test_batched_policy_loop_one_scheduler_per_request():
         dflash_generate_policy_batch(model=m, target=nt, input_ids=prompts, mask_token_id=cfg.mask_token_id,
                                      max_new_tokens=8, stop_token_ids=None, temperature=0.7,
                                      schedulers=[_ewma((8, 16)) for _ in lens])
+
+
+@pytest.mark.parametrize("block_size,lens", [(32, (33, 50)), (24, (40, 18)), (32, (25,)), (20, (21, 64, 30))])
+def test_wide_blocks_in_the_ragged_batch(block_size, lens):
+    """Blocks of 17..32 rows in the batch (VERDICT r2 next #5a; benchmark.py's block-size sweep with several requests per
+    GPU): a request takes two of the group's four 16-row tiles.  Ids and acceptance lengths equal the single-request
+    loop's (which runs these blocks as two tiles of one request), with acceptance plans that accept more than 16 rows,
+    tail clamps through both tiles, and (three prompts) a second group."""
+    from dflash_amd import dflash_generate
+    from dflash_amd.batch import dflash_generate_batch
+    from dflash_amd.synthetic import greedy_walk
+    cfg, m, hf, nt, perm = _setup()
+    n_new = 110
+    prompts, Gs, plans = [], [], []
+    for i, P in enumerate(lens):
+        for seed in range(60 + 10 * i, 70 + 10 * i):     # (a walk that runs into the mask id would be trimmed there)
+            p = torch.randint(0, 2000, (1, P), generator=torch.Generator().manual_seed(seed)).to(dev())
+            G = greedy_walk(perm, p, n_new + 80).to(dev())
+            if int((G[:P + n_new] == cfg.mask_token_id).sum()) == 0:
+                break
+        prompts.append(p)
+        Gs.append(G)
+        plans.append(H.make_plan(64, block_size, 23 + i))
+    assert max(max(pl) for pl in plans) > 16           # some cycles accept into the second tile
+    hooks = [_hook_for(Gs[i], plans[i]) for i in range(len(lens))]
+    singles = [dflash_generate(m, nt, prompts[i], cfg.mask_token_id, n_new, block_size, None, 0.0, draft_token_hook=hooks[i])
+               for i in range(len(lens))]
+
+    def bhook(i, blk, start, call):
+        # the batched block always has 32 slots; the single loop's block is block_size wide and shorter at the tail
+        hooks[i](blk[:, :min(block_size, lens[i] + n_new - start)], start, call)
+
+    outs = dflash_generate_batch(m, nt, prompts, cfg.mask_token_id, n_new, block_size, None, 0.0, draft_token_hook=bhook)
+    for i, (a, b) in enumerate(zip(singles, outs)):
+        assert a.output_ids[0].tolist() == Gs[i][:lens[i] + n_new].tolist(), f"request {i} (single)"
+        assert b.output_ids[0].tolist() == a.output_ids[0].tolist(), f"request {i}"
+        assert b.acceptance_lengths == a.acceptance_lengths, f"request {i}"

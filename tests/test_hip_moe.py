@@ -331,10 +331,11 @@ def test_native_moe_target_end_to_end_lossless_walk():
     assert rq.output_ids[0].tolist() == G[:30 + n_new].tolist() and max(rq.used_block_sizes) > 16
 
 
-def test_moe_target_in_the_ragged_batch():
+@pytest.mark.parametrize("block_size", [16, 24])
+def test_moe_target_in_the_ragged_batch(block_size):
     """An MoE target under dflash_generate_batch (round 3: attention and dense projections of the group in one pass over
-    the weights, the expert MLP per request): every request's committed ids are the target's greedy walk and equal the
-    single-request loop's, acceptance lengths included."""
+    the weights, the expert MLP per request tile): every request's committed ids are the target's greedy walk and equal the
+    single-request loop's, acceptance lengths included.  block_size 24: two tiles per request (blocks of 17..32 rows)."""
     from dflash_amd import DFlashDraftModel, NativeTarget, dflash_generate
     from dflash_amd.batch import dflash_generate_batch
     from dflash_amd.synthetic import greedy_walk, impose_greedy_walk
@@ -348,7 +349,7 @@ def test_moe_target_in_the_ragged_batch():
     prompts = [torch.randint(0, 2000, (1, P), generator=torch.Generator().manual_seed(60 + i)).to(dev())
                for i, P in enumerate(lens)]
     Gs = [greedy_walk(perm, p, n_new + 40).to(dev()) for p in prompts]
-    plans = [H.make_plan(64, 16, 41 + i) for i in range(len(lens))]
+    plans = [H.make_plan(64, block_size, 41 + i) for i in range(len(lens))]
 
     def hook_for(i):
         def hook(blk, start, call):
@@ -360,13 +361,13 @@ def test_moe_target_in_the_ragged_batch():
         return hook
 
     hooks = [hook_for(i) for i in range(len(lens))]
-    singles = [dflash_generate(m, nt, prompts[i], cfg.mask_token_id, n_new, 16, None, 0.0, draft_token_hook=hooks[i])
+    singles = [dflash_generate(m, nt, prompts[i], cfg.mask_token_id, n_new, block_size, None, 0.0, draft_token_hook=hooks[i])
                for i in range(len(lens))]
 
     def bhook(i, blk, start, call):
-        hooks[i](blk[:, :min(16, lens[i] + n_new - start)], start, call)
+        hooks[i](blk[:, :min(block_size, lens[i] + n_new - start)], start, call)
 
-    outs = dflash_generate_batch(m, nt, prompts, cfg.mask_token_id, n_new, 16, None, 0.0, draft_token_hook=bhook)
+    outs = dflash_generate_batch(m, nt, prompts, cfg.mask_token_id, n_new, block_size, None, 0.0, draft_token_hook=bhook)
     for i, (a, b) in enumerate(zip(singles, outs)):
         assert b.output_ids[0].tolist() == a.output_ids[0].tolist() == Gs[i][:lens[i] + n_new].tolist(), f"request {i}"
         assert b.acceptance_lengths == a.acceptance_lengths, f"request {i}"
