@@ -202,8 +202,9 @@ def resolve_cycle_max_candidates(*, enabled, max_candidates, cycle_idx, last_acc
 
 # ----------------------------------------------------------------------------- verify: native target
 class NativeCandidateVerifier:
-    """Up to 4 candidate blocks per pass through the target's weights (`gemm_batch.hip`, request tile = candidate),
-    all on ONE cached prefix; new K/V rows and tapped rows of every candidate staged, the winner's copied in."""
+    """Up to 4 candidate blocks of <= 16 rows (2 of 17..32 rows: two tiles each) per pass through the target's weights
+    (`gemm_batch.hip`, request tile = candidate tile), all on ONE cached prefix; new K/V rows and tapped rows of every
+    candidate staged, the winner's copied in."""
 
     MT = 4
 
@@ -225,21 +226,23 @@ class NativeCandidateVerifier:
         nmax, kmax = max(t.V, 2 * t.I, t.nqkv), max(H, t.I, t.q_dim)
         self.gws = torch.zeros(max(ops.lib().dfl_gemm_batch_ws_bytes(n, k) for n, k in ((nmax, H), (H, kmax))),
                                dtype=torch.uint8, device=dev)
-        self.head_ws = torch.zeros(MT * ops.lib().dfl_attn_head_ws_bytes(t.n_q, max_splits, 1), dtype=torch.uint8,
+        self.head_ws = torch.zeros(MT * ops.lib().dfl_attn_head_ws_bytes(t.n_q, max_splits, 2), dtype=torch.uint8,
                                    device=dev)
-        self.stage_k, self.stage_v = z(t.L, MT, t.n_kv, 16, 128), z(t.L, MT, t.n_kv, 16, 128)
+        self.stage_k, self.stage_v = z(t.L, MT, t.n_kv, 32, 128), z(t.L, MT, t.n_kv, 32, 128)
         self.taps = z(MT, 16, max(1, n_taps) * H)
         self.post = z(MT, 16, dt=I64)
         self.src = dict(xn=ops.brows_frag(self.xn), attn=ops.brows_frag(self.attn), act=ops.brows_frag(self.act))
 
     @torch.inference_mode()
     def verify(self, cands: torch.Tensor, start: int, cache, tap_layers: Sequence[int]) -> torch.Tensor:
-        """cands int64 [C <= 4, bs <= 16] (device) at positions start.. -> posterior ids [C, bs] (a view of the
-        verifier's buffer).  Afterwards stage_k / stage_v [L, c, n_kv, :bs] and taps[c, :bs] hold candidate c's rows."""
+        """cands int64 [C, bs] (device) at positions start.., C <= 4 for bs <= 16, C <= 2 for bs 17..32 -> posterior ids
+        [C, bs] (a view of the verifier's buffer).  Afterwards stage_k / stage_v [L, c, n_kv, :bs] and cand_taps(c, bs)
+        hold candidate c's rows."""
         t, MT, H = self.t, self.MT, self.t.H
         C, bs = cands.shape
-        if not 1 <= C <= MT or not 1 <= bs <= 16:
-            raise ValueError("a pass verifies 1..4 candidates of 1..16 rows")
+        TPR = 1 if bs <= 16 else 2              # 16-row tiles per candidate
+        if not 1 <= bs <= 32 or not 1 <= C <= MT // TPR:
+            raise ValueError("a pass verifies 1..4 candidates of 1..16 rows or 1..2 candidates of 17..32 rows")
         if start + bs > cache.max_rows:
             raise ValueError("target KV cache too small")
         if t.lm_wp is None:
@@ -248,10 +251,10 @@ class NativeCandidateVerifier:
         if tl and max(tl) >= t.L - 1:
             raise NotImplementedError("tapping the last layer (post-norm state) is not supported")
         cos, sin = t._rope_tab(start + bs + 64)
-        rec = [[start, 0, bs, start, start, 0, 0, 0]] * C + [[start, 0, 0, start, start, 0, 0, 0]] * (MT - C)
-        self.dyn.copy_(torch.tensor(rec, dtype=I32))
-        self.ids[:C, :bs].copy_(cands)
-        dyn, s, R = self.dyn, self.src, C
+        rec = [[start, 0, max(0, min(16, bs - 16 * (j % TPR))) if j < C * TPR else 0, start, start, 0, 0, 0] for j in range(MT)]
+        self.dyn.copy_(torch.tensor(rec, dtype=I32))             # one record per TILE (valid rows of the tile)
+        self.ids.view(-1, 16 * TPR)[:C, :bs].copy_(cands)
+        dyn, s, R = self.dyn, self.src, C * TPR
         ops.embed_rows_batch(t.embed, self.ids, R, self.h, H, self.ss_emb, dyn, ops.DYN_BS)
         slots = {}
         for j, l in enumerate(tl):
@@ -268,11 +271,11 @@ class NativeCandidateVerifier:
                                 part=self.part_h if pend else None, N=H, K=pend, tap=ptap, nsplit=pns)
             spread(pdup)
             ops.gemm_resid_batch(lw["qkv"], s["xn"], R, t.nqkv, H, self.xq, add_residual=False, ws=self.gws, dyn=dyn)
-            ops.attn_head_cand(xq=self.xq[:C], q_col=0, k_col=t.q_dim, v_col=t.q_dim + t.kv_dim, n_q=t.n_q, n_kv=t.n_kv,
+            ops.attn_head_cand(xq=self.xq[:R], q_col=0, k_col=t.q_dim, v_col=t.q_dim + t.kv_dim, n_q=t.n_q, n_kv=t.n_kv,
                                q_norm_w=lw["q_norm"], k_norm_w=lw["k_norm"], eps=t.eps, cos_tab=cos, sin_tab=sin,
                                kcache=cache.k[i], vcache=cache.v[i], scale=128 ** -0.5, S=start, bs=bs,
                                ws=self.head_ws, max_splits=self.max_splits, out_frag=self.attn,
-                               k_out=self.stage_k[i], v_out=self.stage_v[i])
+                               k_out=self.stage_k[i], v_out=self.stage_v[i], q_tiles=TPR)
             ops.gemm_f32_batch(lw["o"], s["attn"], R, H, t.q_dim, self.part_h, dyn)
             ops.norm_frag_batch(self.h, R, lw["ln2"], t.eps, self.xn, dyn, ops.DYN_BS, part=self.part_h, N=H, K=t.q_dim)
             if "gu_e" in lw:   # sparse-MoE layer: every candidate routes its own rows (round 3)
@@ -288,7 +291,12 @@ class NativeCandidateVerifier:
                             nsplit=pns)
         spread(pdup)
         ops.gemm_argmax_batch(t.lm_wp, s["xn"], R, t.V, H, 0, 16, self.gws, self.post, 0, dyn, nrows_dyn_word=ops.DYN_BS)
-        return self.post[:C, :bs]
+        return self.post.view(-1, 16 * TPR)[:C, :bs]
+
+    def cand_taps(self, c: int, bs: int) -> torch.Tensor:
+        """Tapped rows [bs padded to its tiles, n_taps * H] of candidate c of the last pass."""
+        tpr = 1 if bs <= 16 else 2
+        return self.taps.view(-1, 16 * tpr, self.taps.shape[2])[c]
 
     def keep(self, win: int, start: int, bs: int, cache) -> None:
         """The winner's new K/V rows become cache rows start..start+bs-1 (the reference keeps the winner's copy of the
@@ -313,8 +321,8 @@ def dflash_generate_candidate_solutions(model, target, input_ids: torch.Tensor, 
     and timing fields of the reference."""
     if temperature >= 1e-5:
         raise ValueError("benchmark_candidate_solutions.py currently supports only temperature=0.0")   # :438-439
-    if block_size > 16:
-        raise ValueError("candidate blocks take 1..16 rows")
+    if block_size > 32:
+        raise ValueError("candidate blocks take 1..32 rows")
     if max_candidates > 8:
         raise ValueError("at most 8 candidates per cycle (dfl_candidate_select)")
     s = DecodeSession(model, target, input_ids, mask_token_id=mask_token_id, max_new_tokens=max_new_tokens,
@@ -326,10 +334,11 @@ def dflash_generate_candidate_solutions(model, target, input_ids: torch.Tensor, 
     ttft = cuda_time() - t0
     native = s.native
     ver = NativeCandidateVerifier(target, len(model.target_layer_ids)) if (native and s.use_draft) else None
-    s.draft_logits = torch.zeros(16, V, dtype=BF16, device=dev) if s.use_draft else None
+    BW = 16 if block_size <= 16 else 32
+    s.draft_logits = torch.zeros(BW, V, dtype=BF16, device=dev) if s.use_draft else None
     result = torch.zeros(12, dtype=I32, device=dev)
-    cand_buf = torch.zeros(8, 16, dtype=I64, device=dev)
-    post_buf = torch.zeros(8, 16, dtype=I64, device=dev)
+    cand_buf = torch.zeros(8, BW, dtype=I64, device=dev)
+    post_buf = torch.zeros(8, BW, dtype=I64, device=dev)
     score_buf = torch.zeros(8, dtype=F32, device=dev)
     decode_start = cuda_time()
     taus, trace, last_ratio, first_done = [], [], None, False
@@ -378,16 +387,17 @@ def dflash_generate_candidate_solutions(model, target, input_ids: torch.Tensor, 
         hs_all = None
         parked = None
         if ver is not None:
-            if C <= ver.MT:
+            per = ver.MT if bs <= 16 else ver.MT // 2     # candidates per pass (blocks of 17..32 rows take two tiles each)
+            if C <= per:
                 post_buf[:C, :bs].copy_(ver.verify(cand_buf[:C, :bs], start, s.tcache, model.target_layer_ids))
-            else:       # two passes of <= 4: each pass's staged rows are set aside before the next overwrites them
+            else:       # several passes: each pass's staged rows are set aside before the next overwrites them
                 parked = []
-                for c0 in range(0, C, ver.MT):
-                    c1 = min(C, c0 + ver.MT)
+                for c0 in range(0, C, per):
+                    c1 = min(C, c0 + per)
                     post_buf[c0:c1, :bs].copy_(ver.verify(cand_buf[c0:c1, :bs], start, s.tcache, model.target_layer_ids))
                     for c in range(c1 - c0):
                         parked.append((ver.stage_k[:, c, :, :bs].clone(), ver.stage_v[:, c, :, :bs].clone(),
-                                       ver.taps[c].clone()))
+                                       ver.cand_taps(c, bs).clone()))
         elif native:   # bs == 1 tail without a draft: the plain verify
             post, _ = target.verify(cand_buf[0, :bs], start, s.tcache)
             post_buf[:1, :bs].copy_(post)
@@ -417,10 +427,10 @@ def dflash_generate_candidate_solutions(model, target, input_ids: torch.Tensor, 
                 winner_taps = tp
             else:
                 ver.keep(win, start, bs, s.tcache)
-                winner_taps = ver.taps[win]
+                winner_taps = ver.cand_taps(win, bs)
             s.tcache.crop(s.start)
             if s.use_draft:
-                s.taps_buf[:16].copy_(winner_taps)
+                s.taps_buf[:winner_taps.shape[0]].copy_(winner_taps)
                 s.target_hidden = s.taps_buf[None, :tau]
         elif native:
             s.tcache.crop(s.start)

@@ -1086,3 +1086,18 @@ extern "C" int dfl_attn_head_batch_t(const void *xq, int64_t ldq, int q_col, int
                           0, DFL_DYN_WORDS, cache_req_stride, stream);
 }
 
+// Candidate blocks of 17..32 rows: candidate c = TWO consecutive 16-row tiles of xq / out_frag; staging rows 0..bs-1.
+extern "C" int dfl_attn_head_cand_t(const void *xq, int64_t ldq, int q_col, int k_col, int v_col, int n_cand,
+                                    int64_t xq_cand_stride, int n_q, int n_kv, const void *q_norm_w, const void *k_norm_w,
+                                    float eps, const void *cos_tab, const void *sin_tab, int max_pos, const void *kcache,
+                                    const void *vcache, int cache_rows, float scale, int S, int bs, void *ws, int max_splits,
+                                    void *out_frag, int64_t out_cand_stride, int64_t out_tile_stride, int q_tiles, void *k_out,
+                                    void *v_out, int64_t kv_out_cand_stride, int out_rows, void *stream) {
+  DFL_REQUIRE(n_cand >= 1 && k_out && v_out, "dfl_attn_head_cand_t: needs the K/V staging area");
+  DFL_REQUIRE(q_tiles == 1 || q_tiles == 2, "dfl_attn_head_cand_t: q_tiles must be 1 or 2");
+  return attn_head_launch(xq, ldq, q_col, k_col, v_col, nullptr, 0, 0, 0, n_q, n_kv, q_norm_w, k_norm_w, eps, cos_tab, sin_tab,
+                          max_pos, const_cast<void *>(kcache), const_cast<void *>(vcache), cache_rows, scale, 1, nullptr, S, 0,
+                          bs, S, q_tiles, ws, max_splits, out_frag, out_tile_stride, n_cand, xq_cand_stride, out_cand_stride, k_out,
+                          v_out, kv_out_cand_stride, out_rows, 0, 0, stream);
+}
+

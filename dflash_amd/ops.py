@@ -316,14 +316,25 @@ def attn_head_oproj(*, xq: torch.Tensor, q_col: int, k_col: int, v_col: int, n_q
 
 def attn_head_cand(*, xq: torch.Tensor, q_col: int, k_col: int, v_col: int, n_q: int, n_kv: int, q_norm_w, k_norm_w, eps,
                    cos_tab, sin_tab, kcache, vcache, scale: float, S: int, bs: int, ws, max_splits: int,
-                   out_frag: torch.Tensor, k_out: torch.Tensor, v_out: torch.Tensor) -> None:
-    """xq [C, 16, ldq] bf16 candidate block rows; out_frag [C, 16*n_q*128]; k_out / v_out [C, n_kv, rows, 128]:
-    the candidates' new K/V rows (rows 0..bs-1), NOT written to the cache."""
+                   out_frag: torch.Tensor, k_out: torch.Tensor, v_out: torch.Tensor, q_tiles: int = 1) -> None:
+    """xq [tiles, 16, ldq] bf16 candidate block rows; out_frag [tiles, 16*n_q*128]; k_out / v_out [C, n_kv, rows, 128]:
+    the candidates' new K/V rows (rows 0..bs-1), NOT written to the cache.  q_tiles = 2 (bs 17..32): candidate c owns tiles
+    2 c, 2 c + 1 of xq / out_frag."""
     assert xq.is_cuda and xq.dtype == BF16 and xq.dim() == 3 and xq.stride(2) == 1 and xq.shape[1] >= 16
     assert out_frag.dim() == 2 and out_frag.is_contiguous() and out_frag.shape[0] >= xq.shape[0]
     assert k_out.shape == v_out.shape and k_out.dim() == 4 and k_out.shape[3] == 128 and k_out.is_contiguous()
-    assert v_out.is_contiguous() and k_out.shape[0] >= xq.shape[0] and k_out.shape[1] == n_kv
+    assert v_out.is_contiguous() and k_out.shape[0] * q_tiles >= xq.shape[0] and k_out.shape[1] == n_kv
     assert kcache.shape == vcache.shape and kcache.dim() == 3 and kcache.shape[2] == 128
+    if q_tiles != 1:
+        assert xq.shape[0] % q_tiles == 0 and k_out.shape[2] >= bs
+        check(lib().dfl_attn_head_cand_t(
+            xq.data_ptr(), xq.stride(1), q_col, k_col, v_col, xq.shape[0] // q_tiles, q_tiles * xq.stride(0), n_q, n_kv,
+            _p(q_norm_w, BF16, "q_norm_w"), _p(k_norm_w, BF16, "k_norm_w"), eps, _p(cos_tab, BF16, "cos"),
+            _p(sin_tab, BF16, "sin"), cos_tab.shape[0], _p(kcache, BF16, "kcache"), _p(vcache, BF16, "vcache"),
+            kcache.shape[1], scale, S, bs, _p(ws), max_splits, _p(out_frag, BF16, "out_frag"), q_tiles * out_frag.stride(0),
+            out_frag.stride(0), q_tiles, _p(k_out, BF16, "k_out"), _p(v_out, BF16, "v_out"), k_out.stride(0), k_out.shape[2],
+            _stream()), "dfl_attn_head_cand_t")
+        return
     check(lib().dfl_attn_head_cand(
         xq.data_ptr(), xq.stride(1), q_col, k_col, v_col, xq.shape[0], xq.stride(0), n_q, n_kv,
         _p(q_norm_w, BF16, "q_norm_w"), _p(k_norm_w, BF16, "k_norm_w"), eps, _p(cos_tab, BF16, "cos"),

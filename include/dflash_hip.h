@@ -263,6 +263,14 @@ int dfl_attn_head_cand(const void *xq, int64_t ldq, int q_col, int k_col, int v_
                        const void *sin_tab, int max_pos, const void *kcache, const void *vcache, int cache_rows,
                        float scale, int S, int bs, void *ws, int max_splits, void *out_frag, int64_t out_cand_stride,
                        void *k_out, void *v_out, int64_t kv_out_cand_stride, int out_rows, void *stream);
+/* The same for candidate blocks of 17..32 rows (q_tiles = 2): candidate c = two consecutive 16-row tiles of xq and of
+ * out_frag (out_tile_stride elements apart); ws: n_cand * dfl_attn_head_ws_bytes(n_q, max_splits, q_tiles) bytes. */
+int dfl_attn_head_cand_t(const void *xq, int64_t ldq, int q_col, int k_col, int v_col, int n_cand, int64_t xq_cand_stride,
+                         int n_q, int n_kv, const void *q_norm_w, const void *k_norm_w, float eps, const void *cos_tab,
+                         const void *sin_tab, int max_pos, const void *kcache, const void *vcache, int cache_rows,
+                         float scale, int S, int bs, void *ws, int max_splits, void *out_frag, int64_t out_cand_stride,
+                         int64_t out_tile_stride, int q_tiles, void *k_out, void *v_out, int64_t kv_out_cand_stride,
+                         int out_rows, void *stream);
 
 /* dfl_attn_head for the R requests of a ragged batch in one launch (grid.z = request; replaces dfl_attn_fused_batch):
  * request r's block rows at xq + r * xq_req_stride, its lengths at dyn + r * DFL_DYN_WORDS (block form: the context rows
