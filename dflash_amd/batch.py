@@ -481,14 +481,14 @@ class BatchedDecoder:
 def dflash_generate_batch(model: DFlashDraftModel, target: NativeTarget, input_ids: Sequence[torch.Tensor],
                           mask_token_id: int, max_new_tokens: int, block_size: int, stop_token_ids,
                           temperature: float = 0.0, draft_token_hook: Optional[Callable] = None,
-                          group_size: int = MAX_GROUP) -> list:
+                          group_size: int = MAX_GROUP, hook_block_view: bool = False) -> list:
     """`dflash_generate` (benchmark.py:44-251) for a list of prompts: requests run in
     groups of `group_size` <= 4 (<= 2 with block sizes of 17..32 rows) that share the weight stream; returns one namespace per
     prompt with the fields of benchmark.py:242-251 (timing fields are the group's).
     draft_token_hook(request_index, block, start, call)."""
-    if not 16 <= block_size <= 32:
-        raise NotImplementedError("the batched loop takes blocks of 16 rows (one tile per request) or 17..32 rows (two)")
-    tpr = 1 if block_size == 16 else 2      # blocks of 17..32 rows: a request takes two of the group's four tiles
+    if not 1 <= block_size <= 32:
+        raise NotImplementedError("the batched loop takes blocks of 1..16 rows (one tile per request) or 17..32 rows (two)")
+    tpr = 1 if block_size <= 16 else 2      # blocks of 17..32 rows: a request takes two of the group's four tiles
     group_size = min(group_size, MAX_GROUP // tpr)
     n = len(input_ids)
     results = [None] * n
@@ -505,7 +505,10 @@ def dflash_generate_batch(model: DFlashDraftModel, target: NativeTarget, input_i
             dec.admit(r, p, temperature)
         ttft = cuda_time() - t0
         taus = [[] for _ in idx]
-        hook = (lambda r, blk, start, call: draft_token_hook(idx[r], blk, start, call)) if draft_token_hook else None
+        # (hook_block_view: the hook sees the block as the single-request loop hands it over, bs slots; default: the
+        # request's whole 16- / 32-slot row)
+        hook = ((lambda r, blk, start, call: draft_token_hook(idx[r], blk[:, :max(1, dec.bs[r])] if hook_block_view else blk,
+                                                              start, call)) if draft_token_hook else None)
         t1 = cuda_time()
         clock = [t1]
         first = True

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void k_pgemm(PGemmArgs a) {
 // row's chunks stay in registers between the sum of squares and the normalisation (one pass over memory; the first
 // form, one workgroup per 16-row tile with 16 threads per row, took 22 us for 1024 x 4096: 64 workgroups, two passes).
 // norm_w == nullptr: pack only.  Rows >= P give zero fragments.  H <= 64 * 8 * PN_MAXC.
-constexpr int PN_MAXC = 8;
+constexpr int PN_MAXC = 16;  // H <= 8192 per call (a row's chunks stay in registers)
 // ks_total / ks0: the tiles' k-step count and the k-step these H columns start at (a column chunk of wider rows).
 __global__ __launch_bounds__(256) void k_pnorm_pack(const bf16_t *h, int64_t ldh, int P, int H, const bf16_t *norm_w,
                                                     float eps, bf16x8 *xf, int ks_total, int ks0) {

@@ -552,6 +552,9 @@ def dflash_generate(model, target, input_ids: torch.Tensor, mask_token_id: int, 
                     block_size: int, stop_token_ids, temperature: float = 0.0, collect_profile: bool = False,
                     draft_steps: int = 1, draft_token_hook=None) -> SimpleNamespace:
     """benchmark.py:44-55 signature; returns the namespace of :242-251."""
+    if getattr(model, "wide_hidden", False):
+        return _generate_wide_hidden(model, target, input_ids, mask_token_id, max_new_tokens, block_size, stop_token_ids,
+                                     temperature, collect_profile, draft_steps, draft_token_hook)
     r = run_decode(model, target, input_ids, mask_token_id=mask_token_id, max_new_tokens=max_new_tokens,
                    block_size=block_size, stop_token_ids=stop_token_ids, temperature=temperature, clamp_tail=True,
                    draft_steps=draft_steps, collect_profile=collect_profile, draft_token_hook=draft_token_hook)
@@ -559,6 +562,23 @@ def dflash_generate(model, target, input_ids: torch.Tensor, mask_token_id: int, 
                            num_output_tokens=r.num_output_tokens, time_to_first_token=r.time_to_first_token,
                            time_per_output_token=r.time_per_output_token, acceptance_lengths=r.acceptance_lengths,
                            cycle_trace=r.cycle_trace, profile_summary=r.profile_summary)
+
+
+def _generate_wide_hidden(model, target, input_ids, mask_token_id, max_new_tokens, block_size, stop_token_ids, temperature,
+                          collect_profile=False, draft_steps=1, draft_token_hook=None) -> SimpleNamespace:
+    """hidden_size > 4096: the request runs as a group of ONE through the ragged-batch kernels (their GEMMs cut K over
+    workgroups; the single-request kernels keep a whole K = hidden row slice per workgroup).  Same loop semantics
+    (benchmark.py:44-251, tail clamp included); no per-cycle profile, one draft step per cycle."""
+    from .batch import dflash_generate_batch
+    from .target import NativeTarget
+    if not isinstance(target, NativeTarget):
+        raise NotImplementedError("hidden_size > 4096: wrap the target in dflash_amd.NativeTarget (the draft forward and the "
+                                  "verify share the ragged-batch launches)")
+    if collect_profile or draft_steps != 1:
+        raise NotImplementedError("hidden_size > 4096: no per-cycle profile and one draft step per cycle")
+    hook = (lambda r, blk, start, call: draft_token_hook(blk, start, call)) if draft_token_hook else None
+    return dflash_generate_batch(model, target, [input_ids], mask_token_id, max_new_tokens, block_size, stop_token_ids,
+                                 temperature, draft_token_hook=hook, group_size=1, hook_block_view=True)[0]
 
 
 def dflash_generate_policy(*, model, target, input_ids: torch.Tensor, mask_token_id: int, max_new_tokens: int,

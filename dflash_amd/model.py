@@ -79,8 +79,10 @@ class DFlashDraftModel:
             raise NotImplementedError("the gfx950 kernels are built for head_dim == 128")
         if c.hidden_size % 32 or c.intermediate_size % 32 or c.vocab_size % 16:
             raise NotImplementedError("need hidden/intermediate % 32 == 0 and vocab % 16 == 0")
-        if c.hidden_size // 32 > 128:
-            raise NotImplementedError("hidden_size > 4096 needs the split-K activation path")
+        # hidden_size > 4096 (a 14B / 32B-class target): the single-request kernels keep a whole K = hidden row slice per
+        # workgroup; such models run through the ragged-batch kernels (K cut over workgroups) as a group of one request:
+        # dflash_generate / spec_generate route there (generate.py), forward() / draft_block() are not available
+        self.wide_hidden = c.hidden_size // 32 > 128
         self.block_size = c.block_size
         self.mask_token_id = c.mask_token_id
         self.target_layer_ids = list(c.target_layer_ids)
@@ -326,7 +328,7 @@ class DFlashDraftModel:
         if (n >= 128 and self.rows_prefill and c.hidden_size % 128 == 0 and c.fc_in % 64 == 0
                 and (c.num_hidden_layers * 2 * c.kv_dim) % 128 == 0 and "kv_all" in self.w):
             return self._prefill_context_rows(cache, th.contiguous(), pos0)
-        if n > 16 and self.wide_prefill:
+        if (n > 16 and self.wide_prefill) or self.wide_hidden:
             return self._prefill_context_wide(cache, th, pos0)
         cos, sin = self._rope_tab(pos0 + n + 64)
         ops.set_dyn(cache.dyn, S, 0, 0, pos0)
@@ -573,7 +575,10 @@ class DFlashDraftModel:
     def spec_generate(self, target, input_ids: torch.LongTensor, max_new_tokens: int, stop_token_ids,
                       temperature: float, draft_token_hook=None) -> torch.LongTensor:
         """model/dflash.py:192-277."""
-        from .generate import run_decode
+        from .generate import _generate_wide_hidden, run_decode
+        if self.wide_hidden:    # (ids are the same with or without the harness form's tail clamp)
+            return _generate_wide_hidden(self, target, input_ids, self.mask_token_id, max_new_tokens, self.block_size,
+                                         stop_token_ids, temperature, draft_token_hook=draft_token_hook).output_ids
         r = run_decode(self, target, input_ids, mask_token_id=self.mask_token_id, max_new_tokens=max_new_tokens,
                        block_size=self.block_size, stop_token_ids=stop_token_ids, temperature=temperature,
                        clamp_tail=False, draft_token_hook=draft_token_hook)

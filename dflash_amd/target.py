@@ -118,8 +118,11 @@ class NativeTarget:
         rope = getattr(cfg, "rope_parameters", None) or {}
         rtype = rope.get("rope_type", "default") if isinstance(rope, dict) else "default"
         theta = (rope.get("rope_theta") if isinstance(rope, dict) else None) or getattr(cfg, "rope_theta", None)
-        if self.hd != 128 or self.H // 32 > 128 or self.H % 32 or (self.I % 32 and not getattr(cfg, "num_experts", 0)) or self.V % 16:
-            raise NotImplementedError("NativeTarget: needs head_dim 128, hidden <= 4096 (%32), vocab %16")
+        if self.hd != 128 or self.H % 32 or (self.I % 32 and not getattr(cfg, "num_experts", 0)) or self.V % 16:
+            raise NotImplementedError("NativeTarget: needs head_dim 128, hidden %32, vocab %16")
+        # hidden > 4096: prefill on the prefill kernels and decode through the ragged-batch kernels (BatchedDecoder, a
+        # group of one request); verify() — the single-request kernels, a whole K = hidden slice per workgroup — is not available
+        self.wide_hidden = self.H // 32 > 128
         # position-only RoPE variants: the cos/sin tables are taken from the wrapped model's own
         # rotary module (Llama-3.1's "llama3" frequency scaling, BASELINE config 4; linear; yarn)
         if rtype not in ("default", "llama3", "linear", "yarn") or (rtype == "default" and theta is None):
@@ -351,9 +354,22 @@ class NativeTarget:
             self.lm_wp = ops.pack_weight(self.lm_head.weight.detach().to(BF16).contiguous())
         t0 = (P - 1) // 16 * 16
         rows = h[t0:t0 + 16]
-        ss = rows.float().pow(2).sum(-1).contiguous()
-        ops.gemm_argmax(self.lm_wp, ops.rows_normed(rows, ss, 1, self.norm, self.eps), self.V, H, 0, 16,
-                        self.ws["argmax_ws"], pf["ids"], 0, logits=pf["logits"])
+        if self.wide_hidden:   # K = hidden cut over workgroups: the ragged-batch form of norm + lm_head, one tile
+            if "wxn" not in pf:
+                pf["wxn"] = torch.zeros(2, 16 * H, dtype=BF16, device=dev)
+                pf["wdyn"] = torch.tensor([[0, 0, 16, 0, 0, 0, 0, 0]] * 2, dtype=torch.int32, device=dev)
+                pf["wgws"] = torch.zeros(ops.lib().dfl_gemm_batch_ws_bytes(self.V, H), dtype=torch.uint8, device=dev)
+                pf["wh"] = torch.zeros(2, 16, H, dtype=BF16, device=dev)
+                pf["wlogits"], pf["wids"] = torch.zeros(2, 16, self.V, dtype=BF16, device=dev), torch.zeros(2, 16, dtype=torch.int64, device=dev)
+            pf["wh"][0].copy_(rows)
+            ops.norm_frag_batch(pf["wh"], 1, self.norm, self.eps, pf["wxn"], pf["wdyn"], ops.DYN_BS)
+            ops.gemm_argmax_batch(self.lm_wp, ops.brows_frag(pf["wxn"]), 1, self.V, H, 0, 16, pf["wgws"], pf["wids"], 0,
+                                  pf["wdyn"], nrows_dyn_word=ops.DYN_BS, logits=pf["wlogits"])
+            pf["logits"].copy_(pf["wlogits"][0])
+        else:
+            ss = rows.float().pow(2).sum(-1).contiguous()
+            ops.gemm_argmax(self.lm_wp, ops.rows_normed(rows, ss, 1, self.norm, self.eps), self.V, H, 0, 16,
+                            self.ws["argmax_ws"], pf["ids"], 0, logits=pf["logits"])
         logits = pf["logits"][P - 1 - t0].clone().view(1, 1, self.V)
         # (hidden_states[L], HF's final-normed state, is not kept: nothing on the path reads it — model/utils.py:16-25
         # taps layer OUTPUTS, and build_target_layer_ids never picks the last layer)
@@ -519,6 +535,9 @@ class NativeTarget:
         (kept by dfl_accept_commit_rearm_t) — `start` is then only an upper bound that sizes the attention's key splits
         and the RoPE table, and the sequence can be captured into a hipGraph (DecodeSession.capture)."""
         bs = block_ids.numel()
+        if self.wide_hidden:
+            raise NotImplementedError("NativeTarget.verify: hidden > 4096 runs through the ragged-batch path "
+                                      "(dflash_generate / dflash_generate_batch / BatchedDecoder)")
         if bs < 1 or bs > 32:
             raise ValueError("verify takes 1..32 block rows")
         if bs > 16 and self.attn_impl != "head":

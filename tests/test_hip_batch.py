@@ -556,3 +556,59 @@ def test_wide_blocks_in_the_ragged_batch(block_size, lens):
         assert a.output_ids[0].tolist() == Gs[i][:lens[i] + n_new].tolist(), f"request {i} (single)"
         assert b.output_ids[0].tolist() == a.output_ids[0].tolist(), f"request {i}"
         assert b.acceptance_lengths == a.acceptance_lengths, f"request {i}"
+
+
+def test_hidden_5120_runs_through_the_ragged_batch_kernels():
+    """hidden_size > 4096 (a 14B / 32B-class target; VERDICT r2 missing #5): the single-request kernels do not take it, the
+    request runs as a group of one through the ragged-batch kernels.  Two layers of Qwen3-32B's widths (H 5120, 64 q / 8 kv
+    heads) + a 2-layer draft of H 5120: native prefill vs the HF forward, then dflash_generate / spec_generate commit the
+    target's greedy walk with the scripted acceptance lengths."""
+    from dflash_amd import DFlashDraftModel, NativeTarget, dflash_generate
+    from dflash_amd.config import DFlashConfig
+    from dflash_amd.synthetic import greedy_walk, impose_greedy_walk, make_hf_qwen3
+    from transformers import DynamicCache
+    dims = dict(vocab_size=2048, hidden_size=5120, num_layers=2, num_heads=64, num_kv_heads=8, head_dim=128,
+                intermediate_size=10240, rope_theta=1e6)
+    torch.manual_seed(13)
+    hf = make_hf_qwen3(dims, dev(), dtype=BF16)
+    nt = NativeTarget(hf)
+    assert nt.wide_hidden and nt.native_prefill
+    P = 130
+    prompt = torch.randint(0, 2000, (1, P), generator=torch.Generator().manual_seed(2)).to(dev())
+    cache = nt.new_cache(P + 64)
+    out = nt.prefill(prompt, cache, output_hidden_states=True, tap_layers=[0])
+    rc = DynamicCache()
+    with torch.inference_mode():
+        ref = hf(prompt, position_ids=torch.arange(P, device=dev())[None], past_key_values=rc, use_cache=True,
+                 logits_to_keep=1, output_hidden_states=True)
+    H.assert_close("H5120 prefill logits (last row)", out.logits[0], ref.logits[0])
+    H.assert_close("H5120 prefill tap layer 0", out.hidden_states[1][0], ref.hidden_states[1][0])
+    H.assert_close("H5120 prefill K layer 1", cache.k[1][:, :P], rc.layers[1].keys[0], max_rel=H.KV_MAX_REL)
+    with pytest.raises(NotImplementedError):
+        nt.verify(prompt[0, :16], P, cache)
+    # the loop: a large-margin greedy walk imposed on the target, scripted acceptance
+    perm = impose_greedy_walk(hf, seed=5)
+    nt = NativeTarget(hf)
+    cfg = DFlashConfig(hidden_size=5120, num_hidden_layers=2, num_attention_heads=40, num_key_value_heads=8, head_dim=128,
+                       intermediate_size=10240, vocab_size=2048, num_target_layers=2, block_size=16, rope_theta=1e6,
+                       mask_token_id=2047, target_layer_ids=[0, 0])
+    m = DFlashDraftModel(cfg, device=dev())
+    m.load_state_dict(H.draft_weights(cfg, seed=3, dtype=BF16))
+    assert m.wide_hidden
+    n_new = 60
+    p2 = torch.randint(0, 2000, (1, 37), generator=torch.Generator().manual_seed(9)).to(dev())
+    G = greedy_walk(perm, p2, n_new + 40).to(dev())
+    plan = H.make_plan(64, 16, 31)
+    hook = _hook_for(G, plan)
+    r = dflash_generate(m, nt, p2, cfg.mask_token_id, n_new, 16, None, 0.0, draft_token_hook=hook)
+    assert r.output_ids[0].tolist() == G[:37 + n_new].tolist()
+    exp, tot, c = [], 0, 0
+    while tot < n_new:
+        t = min(plan[c] + 1, n_new - tot)
+        exp.append(t)
+        tot += t
+        c += 1
+    assert r.acceptance_lengths == exp
+    ids = m.spec_generate(target=nt, input_ids=p2, max_new_tokens=n_new, stop_token_ids=None, temperature=0.0,
+                          draft_token_hook=_hook_for(G, plan))
+    assert ids[0].tolist() == G[:37 + n_new].tolist()
