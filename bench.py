@@ -386,6 +386,19 @@ def batched_leg(args, rank, dev, draft, target, perm, cfg):
     _, cyc_sum = D.reduce_timing(dt, float(args.steps * R), device=dev)
     # lm_head launch: weights once + the fp32 partial tiles of the 2 K parts written and read back
     part = 2 * (151936 // 16) * 4 * 1024 * 2
+    traffic_b, traffic_note = None, "no PMC summary for the current kernel sources"
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    try:    # committed per-launch HBM bytes of this very kernel, accepted while gemm_batch.hip is unchanged (hash)
+        from pmc_kernels_json import BATCH_SOURCES, source_hash
+        for fn in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+            if fn.endswith("_pmc_batch_kernels.json"):
+                rec = json.load(open(os.path.join(ROOT, "profiles", fn)))
+                if rec.get("kernel_source_sha256_16") == source_hash(BATCH_SOURCES) and R == 4:
+                    traffic_b = rec.get("kernels", {}).get("lm_head", {}).get("hbm_bytes_per_launch")
+                    traffic_note = f"profiles/{fn} (kernel sources unchanged since)"
+                    break
+    except Exception as e:
+        traffic_note = f"PMC summary not read: {type(e).__name__}"
     kv_bytes = 20480 * (P + 16)
     hot_bytes = DRAFT_WEIGHT_BYTES + LM_HEAD_BYTES + R * kv_bytes
     return dict(
@@ -393,7 +406,7 @@ def batched_leg(args, rank, dev, draft, target, perm, cfg):
         raw_tau1_value=cyc_sum / dt_max, lossless_fraction=n_ok / max(1, n_all),
         roofline={"kernel": "k_gemm_b<4,EPI_ARGMAX> (lm_head GEMM + fused argmax, 4 request tiles)", "bound": "hbm",
                   "achieved": LM_HEAD_BYTES / (lm_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                  "frac": LM_HEAD_BYTES / (lm_ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
+                  "frac": LM_HEAD_BYTES / (lm_ms * 1e-3) / 1e9 / 8000.0, "traffic": traffic_b,
                   "bytes_per_launch": LM_HEAD_BYTES, "avg_ms": lm_ms,
                   "note": f"algorithmic bytes = the weights; the kernel also moves {part} B of fp32 partial tiles "
                           "(K parts meet through HBM)"},

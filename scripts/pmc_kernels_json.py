@@ -9,20 +9,26 @@ import csv, hashlib, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNEL_SOURCES = ["dflash_amd/csrc/gemm_skinny.hip", "dflash_amd/csrc/gemm_rows.h", "dflash_amd/csrc/dfl_common.h"]
+# --batch: the 4-request leg (bench.py --requests-per-gpu 4): the ragged-batch lm_head / gate-up kernels of gemm_batch.hip
+BATCH_SOURCES = ["dflash_amd/csrc/gemm_batch.hip", "dflash_amd/csrc/gemm_rows.h", "dflash_amd/csrc/dfl_common.h"]
+BATCH_KERNELS = {"lm_head": ("k_gemm_b<4,2>", 151936 * 4096 * 2), "gate_up": ("k_gemm_b<4,1>", 2 * 12288 * 4096 * 2)}
 # (round 3 names: k_gemm<MT, CHUNKED, EPI, NORM>; the normalised-source instantiations are the ones the cycle runs)
 KERNELS = {"gate_up": ("k_gemm<1,false,1,true>", 2 * 12288 * 4096 * 2), "lm_head": ("k_gemm<1,false,2,true>", 151936 * 4096 * 2)}
 
 
-def source_hash():
+def source_hash(sources=None):
     h = hashlib.sha256()
-    for f in KERNEL_SOURCES:
+    for f in (sources or KERNEL_SOURCES):
         h.update(open(os.path.join(ROOT, f), "rb").read())
     return h.hexdigest()[:16]
 
 
 if __name__ == "__main__":
+    if "--batch" in sys.argv:
+        sys.argv.remove("--batch")
+        KERNEL_SOURCES, KERNELS = BATCH_SOURCES, BATCH_KERNELS
     allrows = list(csv.DictReader(open(sys.argv[1])))
-    out = {"kernels": {}, "source": os.path.relpath(sys.argv[1], ROOT), "kernel_source_sha256_16": source_hash(),
+    out = {"kernels": {}, "source": os.path.relpath(sys.argv[1], ROOT), "kernel_source_sha256_16": source_hash(KERNEL_SOURCES),
            "kernel_sources": KERNEL_SOURCES,
            "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (scripts/profile_gpu.sh pmc); "
                      "hbm = 2 * FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE counts half of a wide coalesced read, "
