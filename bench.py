@@ -299,8 +299,9 @@ def gpu_leg(args, rank, world, dev):
         roofline=roofline,
         hot_path={"draft_plus_lm_head_ms_per_cycle": draft_ms, "target_verify_ms_per_cycle": target_ms,
                   "algorithmic_bytes_per_cycle": hot_bytes,
-                  "achieved_GBps": hot_bytes / (draft_ms * 1e-3) / 1e9,
-                  "frac_of_8TBps": hot_bytes / (draft_ms * 1e-3) / 1e9 / 8000.0},
+                  # (a run too short to see a run-ahead draft's event pair — it is collected one cycle later — has none)
+                  "achieved_GBps": hot_bytes / (draft_ms * 1e-3) / 1e9 if draft_ms > 0 else None,
+                  "frac_of_8TBps": hot_bytes / (draft_ms * 1e-3) / 1e9 / 8000.0 if draft_ms > 0 else None},
         ttft_side=ttft_side,
         host_side={"enqueue_ms_per_cycle": 1e3 * host_enq, "poll_wait_ms_per_cycle": 1e3 * host_wait,
                    "note": "host share of a timed cycle (time.perf_counter inside DecodeSession.cycle): Python + ctypes enqueueing "
@@ -411,8 +412,9 @@ def batched_leg(args, rank, dev, draft, target, perm, cfg):
                   "note": f"algorithmic bytes = the weights; the kernel also moves {part} B of fp32 partial tiles "
                           "(K parts meet through HBM)"},
         hot_path={"draft_plus_lm_head_ms_per_cycle": draft_ms, "target_verify_ms_per_cycle": target_ms,
-                  "algorithmic_bytes_per_cycle": hot_bytes, "achieved_GBps": hot_bytes / (draft_ms * 1e-3) / 1e9,
-                  "frac_of_8TBps": hot_bytes / (draft_ms * 1e-3) / 1e9 / 8000.0},
+                  "algorithmic_bytes_per_cycle": hot_bytes,
+                  "achieved_GBps": hot_bytes / (draft_ms * 1e-3) / 1e9 if draft_ms > 0 else None,
+                  "frac_of_8TBps": hot_bytes / (draft_ms * 1e-3) / 1e9 / 8000.0 if draft_ms > 0 else None},
     )
 
 
