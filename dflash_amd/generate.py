@@ -288,6 +288,7 @@ class DecodeSession:
         # no tail clamp even if every token of this block is accepted, no stop tokens to end the request early, a
         # caller-driven block size (a scheduler picks the next size only after this cycle's result: `ahead_ok`)
         if (ahead_ok and self.run_ahead and self._dyn_bs == bs and self.native and want_hidden and self.stop_t is None
+                and getattr(self.model, "attn_impl", "head") == "head"   # (the round-1 stage takes no device-driven lengths)
                 and not self.stop_always and self.draft_temperature < 1e-5 and bs <= 16
                 and start + 2 * bs <= self.max_length and start + self.max_bs + 16 + bs <= self.dcache.max_rows):
             self._draft_ahead(bs)
