@@ -620,8 +620,11 @@ __global__ __launch_bounds__(256) void k_pmoe_gather(const bf16x8 *xf, int KS, c
 }
 
 // one workgroup per row, its four waves a quarter of the columns each
+// sum_out (optional): the rows' fp32 sums are stored there ([P][H]) and h is left alone — the ragged-batch decode path adds
+// them to the residual stream in its next norm launch (one rounding there).
 __global__ __launch_bounds__(256) void k_pmoe_combine(const float *out32, int64_t ld32, const int32_t *posmap, int P, int H,
-                                                      int top_k, bf16_t *h, int64_t ldh, bf16_t *tap, int64_t ldtap) {
+                                                      int top_k, bf16_t *h, int64_t ldh, bf16_t *tap, int64_t ldtap,
+                                                      float *sum_out) {
   const int m = blockIdx.x;
   int pos[8];
 #pragma unroll
@@ -631,16 +634,23 @@ __global__ __launch_bounds__(256) void k_pmoe_combine(const float *out32, int64_
 #pragma unroll
     for (int r = 0; r < 8; ++r)
       v[r] = r < top_k ? *reinterpret_cast<const f32x4 *>(out32 + (int64_t)pos[r] * ld32 + c * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-    bf16_t *hp = h + (int64_t)m * ldh + c * 4;
-    const bf16x4 hv = *reinterpret_cast<const bf16x4 *>(hp);
-    bf16x4 o;
+    f32x4 sum;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float s = 0.f;
 #pragma unroll
       for (int r = 0; r < 8; ++r) s += v[r][j];  // slot order (the padding slots of top_k < 8 add zero)
-      o[j] = f2bf(rbf(bf2f(hv[j]) + rbf(s)));
+      sum[j] = s;
     }
+    if (sum_out) {
+      *reinterpret_cast<f32x4 *>(sum_out + (int64_t)m * H + c * 4) = sum;
+      continue;
+    }
+    bf16_t *hp = h + (int64_t)m * ldh + c * 4;
+    const bf16x4 hv = *reinterpret_cast<const bf16x4 *>(hp);
+    bf16x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = f2bf(rbf(bf2f(hv[j]) + rbf(sum[j])));
     *reinterpret_cast<bf16x4 *>(hp) = o;
     if (tap) *reinterpret_cast<bf16x4 *>(tap + (int64_t)m * ldtap + c * 4) = o;
   }
@@ -874,13 +884,13 @@ extern "C" int dfl_prefill_moe_gemm_down(const void *wp_down_e, int64_t w_expert
 }
 
 extern "C" int dfl_prefill_moe_combine(const float *out32, const int32_t *posmap, int P, int H, int top_k, void *h_io,
-                                       int64_t ldh, void *tap, int64_t ldtap, void *stream) {
-  DFL_REQUIRE(out32 && posmap && h_io, "dfl_prefill_moe_combine: null pointer");
-  DFL_REQUIRE(P >= 1 && H > 0 && H % 4 == 0 && top_k >= 1 && top_k <= 8 && ldh >= H && ldh % 4 == 0 &&
+                                       int64_t ldh, void *tap, int64_t ldtap, float *sum_out, void *stream) {
+  DFL_REQUIRE(out32 && posmap && (h_io || sum_out), "dfl_prefill_moe_combine: null pointer");
+  DFL_REQUIRE(P >= 1 && H > 0 && H % 4 == 0 && top_k >= 1 && top_k <= 8 && (sum_out || (ldh >= H && ldh % 4 == 0)) &&
                   (!tap || (ldtap >= H && ldtap % 4 == 0)),
               "dfl_prefill_moe_combine: bad shape");
   hipLaunchKernelGGL(k_pmoe_combine, dim3(P), dim3(256), 0, (hipStream_t)stream, out32, (int64_t)H, posmap, P, H, top_k,
-                     (bf16_t *)h_io, ldh, (bf16_t *)tap, ldtap);
+                     (bf16_t *)h_io, ldh, (bf16_t *)tap, ldtap, sum_out);
   DFL_CHECK_LAUNCH("dfl_prefill_moe_combine");
   return DFL_OK;
 }

@@ -785,4 +785,4 @@ def prefill_moe_mlp(router_wp, gu_e, down_e, x_frag, P: int, H: int, I: int, E: 
           "dfl_prefill_moe_gemm_down")
     tp, ldt = (None, 0) if tap is None else (_p(tap, BF16, "tap") if tap.is_contiguous() else tap.data_ptr(), tap.stride(0))
     check(L.dfl_prefill_moe_combine(sc["out32"].data_ptr(), sc["posmap"].data_ptr(), P, H, top_k, h_io.data_ptr(),
-                                    h_io.stride(0), tp, ldt, st), "dfl_prefill_moe_combine")
+                                    h_io.stride(0), tp, ldt, None, st), "dfl_prefill_moe_combine")

@@ -429,6 +429,8 @@ int dfl_prefill_attn(const void *q_rows, int64_t ldq, int q_col, const void *kca
  *   dfl_prefill_moe_gemm_down   out32[gathered row][H] = row_w * (act_g Wd_e^T), fp32
  *   dfl_prefill_moe_combine     h[m] = bf16(h[m] + bf16(sum over the row's k slots of out32)) (+ tap copy): the sum over
  *                               experts is rounded once (HF: per-expert bf16 adds), as in dfl_moe_down's consumer.
+ *                               sum_out != NULL: the fp32 sums [P][H] are stored there instead and h is left alone (the
+ *                               ragged-batch decode path adds them in its next dfl_norm_frag_batch).
  * Scratch is caller-owned: cnt / tile_off int32 [E], items int32 [3 * max_items], src_row int32 / row_w float
  * [max_tiles * 16], xg bf16 [max_tiles * 16 * H], act_g bf16 [max_tiles * 16 * I], out32 float [max_tiles * 16 * H].
  * rows_per_item: 64 or 128 rows of one expert per work item (4 or 8 gathered tiles), the same in the three calls of a
@@ -447,7 +449,7 @@ int dfl_prefill_moe_gemm_down(const void *wp_down_e, int64_t w_expert_stride, co
                               const int32_t *n_items, int max_items, int H, int I, const float *row_w, float *out32,
                               int rows_per_item, void *stream);
 int dfl_prefill_moe_combine(const float *out32, const int32_t *posmap, int P, int H, int top_k, void *h_io, int64_t ldh,
-                            void *tap, int64_t ldtap, void *stream);
+                            void *tap, int64_t ldtap, float *sum_out, void *stream);
 
 /* ======================================================================================
  * Ragged batch of requests on one GPU (BASELINE.json configs[2]; SURVEY.md §8e: "within a

@@ -268,15 +268,19 @@ def _moe_target():
     return TM._moe_hf(mlp_only=(1,))
 
 
-def test_native_candidate_pass_on_moe_target_equals_single_verifies():
+@pytest.mark.parametrize("shared_pass", [False, True])
+def test_native_candidate_pass_on_moe_target_equals_single_verifies(shared_pass):
     """The one-pass candidate verify on a sparse-MoE target (round 3: VERDICT r2 "missing" #3 — it fell back to the HF
     forward on a batch-expanded cache): 3 candidate blocks in one pass vs NativeTarget.verify of each block alone on the
-    same prefix.  Every candidate routes its own rows; rows whose expert choice could flip on a bf16 near-tie are not
-    screened out here because both sides run the SAME router kernel on the same fragments."""
+    same prefix.  shared_pass False: every candidate routes its own rows through the per-tile kernels — the SAME router
+    kernel on the same fragments as the single verify, so no near-tie can flip.  True (the default from three tiles on):
+    the 48 rows go through ONE pass over the experts (the prefill's grouped kernels); the router logits then come from the
+    batch GEMM (another fp32 summation order), a near-tie at the k-th place may flip for a row, and the max bar is wider."""
     from dflash_amd import NativeTarget
     from dflash_amd.candidates import NativeCandidateVerifier
     hf = _moe_target()
     nt = NativeTarget(hf)
+    nt.moe_shared_pass = shared_pass
     g = torch.Generator().manual_seed(16)
     P, bs = 45, 16
     prompt = torch.randint(0, 2000, (1, P), generator=g).to(dev())
@@ -295,8 +299,9 @@ def test_native_candidate_pass_on_moe_target_equals_single_verifies():
         nt.verify(cands[c], P, c2, tap_layers=taps, logits_out=logits)
         _, th = nt.verify(cands[c], P, c2, tap_layers=taps, logits_out=logits)
         H.assert_ids_match_where_safe(f"MoE candidate {c} posterior", post[c], logits[:bs].float())
-        H.assert_close(f"MoE candidate {c} taps", ver.taps[c], th[:16])
-        H.assert_close(f"MoE candidate {c} staged K l3", ver.stage_k[3, c, :, :bs], c2.k[3][:, P:P + bs], max_rel=H.KV_MAX_REL)
+        H.assert_close(f"MoE candidate {c} taps", ver.taps[c], th[:16], max_rel=6e-2 if shared_pass else H.MAX_REL)
+        H.assert_close(f"MoE candidate {c} staged K l3", ver.stage_k[3, c, :, :bs], c2.k[3][:, P:P + bs],
+                       max_rel=6e-2 if shared_pass else H.KV_MAX_REL)
 
 
 def test_candidate_loop_is_lossless_on_native_moe_target():

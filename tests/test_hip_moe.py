@@ -538,7 +538,7 @@ def test_moe_prefill_pieces_are_exact_on_integers(rows_per_item, P, skew):
             assert torch.allclose(got, want, rtol=2e-2, atol=2e-2 * float(want.abs().max() + 1)), (m, r)   # (silu: __expf vs torch)
             total[m] += got
     ops.check(L.dfl_prefill_moe_combine(sc["out32"].data_ptr(), sc["posmap"].data_ptr(), P, Hd, k, h.data_ptr(), h.stride(0),
-                                        None, 0, st), "combine")
+                                        None, 0, None, st), "combine")
     want_h = (h0.to(BF16).float() + total.to(BF16).float()).to(BF16)
     assert torch.equal(h[:P].cpu(), want_h)
     assert int(h[P:].abs().sum()) == 0
