@@ -91,7 +91,7 @@ SIGNATURES = {
     "dfl_prefill_moe_max_items": (_i64, [_i, _i, _i]),
     "dfl_prefill_moe_route": (_i, [_p, _i64, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "dfl_prefill_moe_gather": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p]),
-    "dfl_prefill_moe_gemm_silu": (_i, [_p, _i64, _p, _p, _p, _i, _i, _i, _p, _i, _p]),
+    "dfl_prefill_moe_gemm_silu": (_i, [_p, _i64, _p, _p, _p, _i, _i, _i, _p, _i, _p, _p, _p]),
     "dfl_prefill_moe_gemm_down": (_i, [_p, _i64, _p, _p, _p, _i, _i, _i, _p, _p, _i, _p]),
     "dfl_prefill_moe_combine": (_i, [_p, _p, _i, _i, _i, _p, _i64, _p, _i64, _p, _p]),
     # ---- ragged batch of requests

@@ -35,6 +35,8 @@ struct PGemmArgs {
   // row block comes from a device-built work list of (expert, first gathered tile, tiles <= 4) items
   const int32_t *items, *n_items;
   int64_t w_expert_stride;  // bf16x8 units between the experts' packed weights
+  const int32_t *src_row;   // optional: xf holds the UNGATHERED row tiles and gathered row g is source row src_row[g] (< 0: a
+  const bf16x8 *zeros;      //   padding row, read from this 1 KiB of zeros) — the gather happens in the LDS-DMA addresses
   float *out32;             // SCALE32: out32[gathered row][n] = routing weight of the row x sum (fp32, no rounding)
   const float *row_w;       // [gathered row]
   int64_t ld32;
@@ -152,6 +154,18 @@ __global__ __launch_bounds__(256) void k_pgemm(PGemmArgs a) {
   const int wn = w & 1, wm = w >> 1;  // the wave's 64 columns x 64 rows inside the block tile
   const int KT = a.KS >> 1;           // 64-deep steps
 
+  // Gather in the addresses (grouped form, a.src_row): this wave stages the X fragments of tiles 2 q + (w >> 1), k-step
+  // w & 1 (slot = 4 i + w below); lane (g = l >> 4, row r = l & 15) of such a fragment is 16 bytes of SOURCE row
+  // m = src_row[tile * 16 + r], i.e. lane g * 16 + (m & 15) of fragment (m >> 4, k-step) of the ungathered tiles.
+  int64_t xsrc[MB / 2];  // element offset (bf16x8 units) of this lane's piece at k-step 0; < 0: a padding row
+#pragma unroll
+  for (int q = 0; q < MB / 2; ++q) {
+    xsrc[q] = -1;
+    if (GRP && a.src_row) {
+      const int m = a.src_row[tile_of(2 * q + (w >> 1)) * 16 + (l & 15)];
+      if (m >= 0) xsrc[q] = ((int64_t)(m >> 4) * a.KS) * 64 + (l >> 4) * 16 + (m & 15);
+    }
+  }
   // stage kt -> buffer: 16 weight fragments + 2 MB activation fragments of 1 KiB, dealt round-robin to the 4 waves
   auto stage = [&](int kt, int buf) {
 #pragma unroll
@@ -160,6 +174,10 @@ __global__ __launch_bounds__(256) void k_pgemm(PGemmArgs a) {
       const int s16 = slot < 16 ? slot : slot - 16;  // fragment of its operand: (tile s16 >> 1, k-step s16 & 1)
       const bf16x8 *src = (slot < 16 ? wbase + ((size_t)(nb * 8 + (s16 >> 1)) * a.KS + kt * 2 + (s16 & 1)) * 64
                                      : a.xf + ((size_t)tile_of(s16 >> 1) * a.KS + kt * 2 + (s16 & 1)) * 64) + l;
+      if (GRP && i >= 4 && a.src_row) {
+        const int64_t o = xsrc[i >= 4 ? i - 4 : 0];
+        src = o < 0 ? a.zeros + l : a.xf + o + (kt * 2 + (w & 1)) * 64;
+      }
       __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)&lds[buf][slot][0], 16, 0, 0);
     }
   };
@@ -846,8 +864,11 @@ extern "C" int dfl_prefill_moe_gather(const void *x_frag, int P, int H, int top_
 
 extern "C" int dfl_prefill_moe_gemm_silu(const void *wp_gateup_e, int64_t w_expert_stride, const void *xg, const int32_t *items,
                                          const int32_t *n_items, int max_items, int I, int K, void *act_g, int rows_per_item,
-                                         void *stream) {
+                                         const int32_t *src_row, const void *zeros_1k, void *stream) {
   PGemmArgs a{};
+  DFL_REQUIRE(!src_row == !zeros_1k, "dfl_prefill_moe_gemm_silu: src_row and zeros_1k come together");
+  a.src_row = src_row;
+  a.zeros = (const bf16x8 *)zeros_1k;
   DFL_REQUIRE(rows_per_item == 64 || rows_per_item == 128, "dfl_prefill_moe_gemm_silu: rows_per_item must be 64 or 128");
   DFL_REQUIRE(act_g && I > 0 && I % 64 == 0, "dfl_prefill_moe_gemm_silu: need I%%64==0");
   if (!pmoe_gemm_fill(a, wp_gateup_e, w_expert_stride, xg, items, n_items, max_items, 2 * I, K, "dfl_prefill_moe_gemm_silu"))

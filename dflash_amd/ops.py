@@ -749,7 +749,8 @@ def prefill_moe_scratch(P: int, H: int, I: int, E: int, top_k: int, router_cols:
                 rlog=torch.zeros(prefill_rows_padded(P), router_cols, dtype=BF16, device=device),
                 pair_e=zi(P, 8), posmap=zi(P, 8), pair_w=zf(P, 8), cnt=zi(E), tile_off=zi(E), src_row=zi(mt * 16),
                 items=zi(3 * mi), n_items=zi(2), xg=torch.zeros(mt * 16 * H, dtype=BF16, device=device),
-                act_g=torch.zeros(mt * 16 * I, dtype=BF16, device=device), row_w=zf(mt * 16), out32=zf(mt * 16, H))
+                act_g=torch.zeros(mt * 16 * I, dtype=BF16, device=device), row_w=zf(mt * 16), out32=zf(mt * 16, H),
+                zeros=torch.zeros(512, dtype=BF16, device=device))
 
 
 def prefill_moe_route(rlog: torch.Tensor, P: int, sc: dict, norm_topk: bool = True) -> None:
@@ -773,12 +774,15 @@ def prefill_moe_mlp(router_wp, gu_e, down_e, x_frag, P: int, H: int, I: int, E: 
     rlog = sc["rlog"]
     prefill_gemm_rows(router_wp, x_frag, P, rlog.shape[1], H, rlog)
     prefill_moe_route(rlog, P, sc, norm_topk)
+    # The rows are gathered per expert into a copy (xg) that the expert's column blocks then read coalesced.  Gathering
+    # inside the gate/up GEMM's LDS-DMA addresses instead (src_row: no gather launch, no copy) was measured at P = 1024
+    # on the 30B-A3B widths, same box: 455 -> 479 us per layer — every column block re-reads the rows as scattered 16-byte
+    # pieces; it is what the <= 64 decode rows of NativeTarget._moe_mlp_shared use (241 -> 233 us there).
     check(L.dfl_prefill_moe_gather(_p(x_frag, BF16, "x_frag"), P, H, top_k, E, sc["src_row"].data_ptr(), sc["n_items"].data_ptr(),
                                    sc["xg"].data_ptr(), st), "dfl_prefill_moe_gather")
     check(L.dfl_prefill_moe_gemm_silu(_p(gu_e, BF16, "gu_e"), gu_e.stride(0), sc["xg"].data_ptr(), sc["items"].data_ptr(),
                                       sc["n_items"].data_ptr(), sc["max_items"], I, H, sc["act_g"].data_ptr(),
-                                      sc["rows_per_item"], st),
-          "dfl_prefill_moe_gemm_silu")
+                                      sc["rows_per_item"], None, None, st), "dfl_prefill_moe_gemm_silu")
     check(L.dfl_prefill_moe_gemm_down(_p(down_e, BF16, "down_e"), down_e.stride(0), sc["act_g"].data_ptr(),
                                       sc["items"].data_ptr(), sc["n_items"].data_ptr(), sc["max_items"], H, I,
                                       sc["row_w"].data_ptr(), sc["out32"].data_ptr(), sc["rows_per_item"], st),

@@ -466,12 +466,11 @@ class NativeTarget:
         ops.gemm_resid_batch(lw["router_p"], ops.brows_frag(xn), R, sh["rlog"].shape[2], H, sh["rlog"], add_residual=False,
                              ws=sh["gws"], dyn=dyn)
         ops.prefill_moe_route(sh["rlog"].view(64, -1), P, sc, self.norm_topk)
-        ops.check(L.dfl_prefill_moe_gather(xn.data_ptr(), P, H, self.top_k, self.E, sc["src_row"].data_ptr(),
-                                           sc["n_items"].data_ptr(), sc["xg"].data_ptr(), st), "dfl_prefill_moe_gather")
         gu, dn = lw["gu_e"], lw["down_e"]
-        ops.check(L.dfl_prefill_moe_gemm_silu(gu.data_ptr(), gu.stride(0), sc["xg"].data_ptr(), sc["items"].data_ptr(),
+        ops.check(L.dfl_prefill_moe_gemm_silu(gu.data_ptr(), gu.stride(0), xn.data_ptr(), sc["items"].data_ptr(),
                                               sc["n_items"].data_ptr(), sc["max_items"], self.Ie, H, sc["act_g"].data_ptr(),
-                                              sc["rows_per_item"], st), "dfl_prefill_moe_gemm_silu")
+                                              sc["rows_per_item"], sc["src_row"].data_ptr(), sc["zeros"].data_ptr(), st),
+                  "dfl_prefill_moe_gemm_silu")
         ops.check(L.dfl_prefill_moe_gemm_down(dn.data_ptr(), dn.stride(0), sc["act_g"].data_ptr(), sc["items"].data_ptr(),
                                               sc["n_items"].data_ptr(), sc["max_items"], H, self.Ie, sc["row_w"].data_ptr(),
                                               sc["out32"].data_ptr(), sc["rows_per_item"], st), "dfl_prefill_moe_gemm_down")

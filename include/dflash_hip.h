@@ -425,7 +425,9 @@ int dfl_prefill_attn(const void *q_rows, int64_t ldq, int q_col, const void *kca
  *                           [P][8] = gathered row of each pair, src_row / row_w [gathered row] = its source row (-1:
  *                           padding) and routing weight (bf16 value, as float)
  *   dfl_prefill_moe_gather  the source rows' normalised fragments into the gathered tiles xg (zero for padding rows)
- *   dfl_prefill_moe_gemm_silu   act_g = silu(xg Wg_e^T) * (xg Wu_e^T) per expert (gate/up interleaved as dfl_pack_weight_gateup)
+ *   dfl_prefill_moe_gemm_silu   act_g = silu(xg Wg_e^T) * (xg Wu_e^T) per expert (gate/up interleaved as dfl_pack_weight_gateup);
+ *                               with src_row (and 1 KiB of zeros for padding rows) `xg` is the UNGATHERED x_frag and the
+ *                               gather happens in the kernel's LDS-DMA addresses: no dfl_prefill_moe_gather call, no xg
  *   dfl_prefill_moe_gemm_down   out32[gathered row][H] = row_w * (act_g Wd_e^T), fp32
  *   dfl_prefill_moe_combine     h[m] = bf16(h[m] + bf16(sum over the row's k slots of out32)) (+ tap copy): the sum over
  *                               experts is rounded once (HF: per-expert bf16 adds), as in dfl_moe_down's consumer.
@@ -444,7 +446,7 @@ int dfl_prefill_moe_gather(const void *x_frag, int P, int H, int top_k, int E, c
                            void *xg, void *stream);
 int dfl_prefill_moe_gemm_silu(const void *wp_gateup_e, int64_t w_expert_stride, const void *xg, const int32_t *items,
                               const int32_t *n_items, int max_items, int I, int K, void *act_g, int rows_per_item,
-                              void *stream);
+                              const int32_t *src_row, const void *zeros_1k, void *stream);
 int dfl_prefill_moe_gemm_down(const void *wp_down_e, int64_t w_expert_stride, const void *act_g, const int32_t *items,
                               const int32_t *n_items, int max_items, int H, int I, const float *row_w, float *out32,
                               int rows_per_item, void *stream);

@@ -514,9 +514,16 @@ def test_moe_prefill_pieces_are_exact_on_integers(rows_per_item, P, skew):
     # the remaining calls through the product wrapper would recompute the router GEMM: call the pieces
     ops.check(L.dfl_prefill_moe_gather(xf.data_ptr(), P, Hd, k, E, sc["src_row"].data_ptr(), sc["n_items"].data_ptr(),
                                        sc["xg"].data_ptr(), st), "gather")
+    # (gathered copy xg as the operand — the product gathers in the kernel's LDS-DMA addresses instead: second call below)
     ops.check(L.dfl_prefill_moe_gemm_silu(gu_e.data_ptr(), gu_e.stride(0), sc["xg"].data_ptr(), sc["items"].data_ptr(),
-                                          sc["n_items"].data_ptr(), sc["max_items"], Ie, Hd, sc["act_g"].data_ptr(), rows_per_item, st),
-              "silu")
+                                          sc["n_items"].data_ptr(), sc["max_items"], Ie, Hd, sc["act_g"].data_ptr(), rows_per_item,
+                                          None, None, st), "silu")
+    act_from_copy = sc["act_g"][:n_tiles * 16 * Ie].clone()
+    sc["act_g"].zero_()
+    ops.check(L.dfl_prefill_moe_gemm_silu(gu_e.data_ptr(), gu_e.stride(0), xf.data_ptr(), sc["items"].data_ptr(),
+                                          sc["n_items"].data_ptr(), sc["max_items"], Ie, Hd, sc["act_g"].data_ptr(), rows_per_item,
+                                          sc["src_row"].data_ptr(), sc["zeros"].data_ptr(), st), "silu (gather in the addresses)")
+    assert torch.equal(sc["act_g"][:n_tiles * 16 * Ie], act_from_copy)
     ops.check(L.dfl_prefill_moe_gemm_down(down_e.data_ptr(), down_e.stride(0), sc["act_g"].data_ptr(), sc["items"].data_ptr(),
                                           sc["n_items"].data_ptr(), sc["max_items"], Hd, Ie, sc["row_w"].data_ptr(),
                                           sc["out32"].data_ptr(), rows_per_item, st), "down")
