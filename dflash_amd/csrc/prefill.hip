@@ -563,10 +563,21 @@ __global__ __launch_bounds__(1024) void k_pmoe_plan(const int32_t *pair_e, const
   }
   __syncthreads();
   const int npair = P * top_k;
-  // (ranks are kept in posmap until the offsets are known)
-  for (int i = tid; i < npair; i += 1024) {
-    const int m = i / top_k, r = i - m * top_k;
-    posmap[m * 8 + r] = atomicAdd(&cnt[pair_e[m * 8 + r]], 1);
+  // (ranks are kept in posmap until the offsets are known; eight pairs per thread and pass, their loads requested
+  // together.  The kernel stays at 13 - 19 us for the 8192 pairs of a 1k-row prompt either way: one workgroup, and its LDS
+  // atomics meet on 128 counters)
+  for (int i0 = tid; i0 < npair; i0 += 8 * 1024) {
+    int e[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * 1024, m = i / top_k, r = i - m * top_k;
+      e[u] = i < npair ? pair_e[m * 8 + r] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * 1024, m = i / top_k, r = i - m * top_k;
+      if (i < npair) posmap[m * 8 + r] = atomicAdd(&cnt[e[u]], 1);
+    }
   }
   __syncthreads();
   if (tid < 64) {  // one wave: exclusive prefix of tiles and of work items over the experts, 4 experts per lane
@@ -615,12 +626,26 @@ __global__ __launch_bounds__(1024) void k_pmoe_plan(const int32_t *pair_e, const
       items[3 * w + 2] = nt - b < tpi ? nt - b : tpi;
     }
   }
-  for (int i = tid; i < npair; i += 1024) {
-    const int m = i / top_k, r = i - m * top_k;
-    const int pos = toff[pair_e[m * 8 + r]] * 16 + posmap[m * 8 + r];
-    posmap[m * 8 + r] = pos;
-    src_row[pos] = m;
-    row_w[pos] = pair_w[m * 8 + r];
+  for (int i0 = tid; i0 < npair; i0 += 8 * 1024) {
+    int e[8], rk[8];
+    float wv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * 1024, m = i / top_k, r = i - m * top_k, k = i < npair ? m * 8 + r : 0;
+      e[u] = pair_e[k];
+      rk[u] = posmap[k];
+      wv[u] = pair_w[k];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * 1024, m = i / top_k, r = i - m * top_k;
+      if (i < npair) {
+        const int pos = toff[e[u]] * 16 + rk[u];
+        posmap[m * 8 + r] = pos;
+        src_row[pos] = m;
+        row_w[pos] = wv[u];
+      }
+    }
   }
 }
 
