@@ -125,6 +125,24 @@ def gpu_leg(args, rank, world, dev):
     torch.cuda.synchronize()
     log(f"[rank {rank}] models ready in {time.time() - t0:.1f}s")
 
+    # diagnostic knob (DESIGN.md "second stream / captured graph" A/B; never set by the driver): put the process into one
+    # of the states profiles/r3_graph_ab.txt blamed for slower kernels before anything is timed
+    extra = os.environ.get("DFL_BENCH_EXTRA_STREAM", "")
+    if extra:
+        keep = gpu_leg.__dict__.setdefault("_keep", {})
+        if extra in ("idle", "used"):
+            keep["s2"] = torch.cuda.Stream()
+        if extra == "used":
+            with torch.cuda.stream(keep["s2"]):
+                keep["t"] = torch.zeros(64, device=dev) + 1
+            keep["s2"].synchronize()
+        if extra == "graph1":      # a one-kernel torch graph, captured and never replayed
+            g1, y = torch.cuda.CUDAGraph(), torch.zeros(64, device=dev)
+            with torch.cuda.graph(g1):
+                y += 1
+            keep["g1"] = (g1, y)
+        torch.cuda.synchronize()
+
     if args.requests_per_gpu > 1:
         return batched_leg(args, rank, dev, draft, target, perm, cfg)
 

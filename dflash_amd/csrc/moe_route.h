@@ -54,6 +54,10 @@ __device__ __forceinline__ void route_row(const bf16_t *logits_row, int E, int t
         bi = oi;
       }
     }
+    if (bi == 0x7fffffff) {  // a NaN row (one NaN logit makes every probability NaN): no comparison succeeded.  The index
+      bi = r;                // feeds LDS / global counters downstream (k_pmoe_plan, k_moe_route), so it must stay < E: round
+      bv = p[0] + p[1];      // r takes expert r (distinct per round, top_k <= E) with a NaN weight — the NaN propagates
+    }                        // through the expert sums as it does through torch.topk + index_add_, nothing faults
     sel_v[r] = bv;
     sel_i[r] = bi;
     tot += bv;

@@ -572,6 +572,7 @@ __global__ __launch_bounds__(1024) void k_pmoe_plan(const int32_t *pair_e, const
     for (int u = 0; u < 8; ++u) {
       const int i = i0 + u * 1024, m = i / top_k, r = i - m * top_k;
       e[u] = i < npair ? pair_e[m * 8 + r] : 0;
+      e[u] = (unsigned)e[u] < (unsigned)E ? e[u] : 0;  // (route_row keeps its indices < E even for NaN rows; never index LDS by a foreign value)
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -633,6 +634,7 @@ __global__ __launch_bounds__(1024) void k_pmoe_plan(const int32_t *pair_e, const
     for (int u = 0; u < 8; ++u) {
       const int i = i0 + u * 1024, m = i / top_k, r = i - m * top_k, k = i < npair ? m * 8 + r : 0;
       e[u] = pair_e[k];
+      e[u] = (unsigned)e[u] < (unsigned)E ? e[u] : 0;
       rk[u] = posmap[k];
       wv[u] = pair_w[k];
     }

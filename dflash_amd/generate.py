@@ -318,9 +318,22 @@ class DecodeSession:
     def _graph_ok(self, bs: int) -> bool:
         """A cycle that can be replayed: fixed block size, T = 0, no stop ids, no tail clamp even if every token of this
         block and the next is accepted, and the previous cycle left this cycle's draft enqueued (run-ahead)."""
-        return (self.native and self.use_draft and bs == getattr(self, "_graph_bs", None) and self._ahead == bs
+        if not (self.native and self.use_draft and bs == getattr(self, "_graph_bs", None) and self._ahead == bs
                 and self.stop_t is None and not self.stop_always and self.temperature < 1e-5 and self.events is None
-                and self.start + 2 * bs <= self.max_length and self.start + bs <= self._graph_bound)
+                and self.start + 2 * bs <= self.max_length and self.start + bs <= self._graph_bound):
+            return False
+        # The graphs hold RAW device pointers.  A shared draft model / NativeTarget replaces its RoPE table when another
+        # caller needs more positions (`_rope_tab`), and several sessions may interleave on one target: a replaced table
+        # means the captured launches would read freed (possibly reused) memory.  The session keeps the captured
+        # tensors alive (`_graph_keep`), so the replay stays memory-safe in any case; a differing pointer only says the
+        # owner has moved on to a larger table — its first rows are identical, the replay is still right, but the
+        # session re-captures at the next opportunity instead of pinning the old table for ever.
+        m, t = self.model, self.target
+        if m._rope is None or t._rope is None or (m._rope[0].data_ptr(), t._rope[0].data_ptr()) != self._graph_rope:
+            self._graph_bs = None      # run_decode captures again on the next replayable cycle; this one runs eagerly
+            self._graphs, self._graph_keep = {}, None
+            return False
+        return True
 
     @torch.inference_mode()
     def capture(self, bs: int) -> None:
@@ -368,6 +381,11 @@ class DecodeSession:
                 fn()
             self._graphs[name] = g
         self._graph_bs = bs
+        # every tensor whose address sits in the captured launches and that this session does not own through another
+        # attribute: the RoPE tables and the shared workspaces of the draft model and of the target
+        self._graph_rope = (m._rope[0].data_ptr(), t._rope[0].data_ptr())
+        self._graph_keep = (m._rope, t._rope, getattr(m, "ws", None), getattr(t, "ws", None), getattr(t, "_taps", None),
+                            self.lm_wp, self.embed_w, getattr(t, "lm_wp", None))
 
     @torch.inference_mode()
     def cycle_graph(self, bs: int) -> SimpleNamespace:
@@ -472,8 +490,11 @@ def run_decode(model, target, input_ids: torch.Tensor, *, mask_token_id: int, ma
                 s.capture(bs)
             r = s.cycle_graph(bs)
         else:
+            # (collect_profile: no run-ahead draft — its event pairs would be recorded during cycle N and handed to
+            # cycle N + 1, outside that cycle's [cycle0, cycle1] marks; benchmark.py:149-160 times each phase inside its
+            # own cycle)
             r = s.cycle(bs, draft_steps=draft_steps, want_hidden=want_hidden, after_draft=after_draft,
-                        ahead_ok=scheduler is None and draft_steps == 1)
+                        ahead_ok=scheduler is None and draft_steps == 1 and not collect_profile)
         taus.append(r.tau)
         used_bs.append(bs)
         lgens.append(lg[0])

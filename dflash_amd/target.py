@@ -432,7 +432,14 @@ class NativeTarget:
         w, ns, H = self.ws, self.moe_nsplit, self.H
         if R >= self.moe_shared_min and self.moe_shared_pass and H % 128 == 0 and self.Ie % 64 == 0:
             return self._moe_mlp_shared(lw, R, MT, dyn, xn, part)
-        pv = part[:ns * MT * 16 * H].view(ns, MT * 16, H)
+        # The share stride is what the consumer reads with — dfl_norm_frag_batch(nsplit=ns) strides by
+        # batch_tiles(R) * 16 * H (ops.norm_frag_batch) — NOT the caller's tile-slot count: a candidate verifier
+        # always allocates MT = 4 slots, and for R <= 2 (batch_tiles = 2) share 1 would otherwise land at 64 H
+        # while it is read at 32 H (half of the experts' down projections dropped).
+        mt = ops.batch_tiles(R)
+        if mt > MT:
+            raise ValueError(f"moe_mlp_tiles: {R} tiles need {mt} tile slots, the buffers have {MT}")
+        pv = part[:ns * mt * 16 * H].view(ns, mt * 16, H)
         for r in range(R):
             dt, x = dyn[r], xn[r]
             ops.gemm_resid(lw["router"], ops.rows_frag(x), w["rlog"].shape[2], H, w["rlog"][0], add_residual=False, dyn=dt)

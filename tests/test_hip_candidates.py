@@ -268,11 +268,14 @@ def _moe_target():
     return TM._moe_hf(mlp_only=(1,))
 
 
+@pytest.mark.parametrize("C", [1, 2, 3])
 @pytest.mark.parametrize("shared_pass", [False, True])
-def test_native_candidate_pass_on_moe_target_equals_single_verifies(shared_pass):
+def test_native_candidate_pass_on_moe_target_equals_single_verifies(shared_pass, C):
     """The one-pass candidate verify on a sparse-MoE target (round 3: VERDICT r2 "missing" #3 — it fell back to the HF
-    forward on a batch-expanded cache): 3 candidate blocks in one pass vs NativeTarget.verify of each block alone on the
-    same prefix.  shared_pass False: every candidate routes its own rows through the per-tile kernels — the SAME router
+    forward on a batch-expanded cache): C candidate blocks in one pass vs NativeTarget.verify of each block alone on the
+    same prefix.  C = 1 and C = 2: the verifier always holds four tile slots while the norm launch
+    behind the experts strides the expert shares by batch_tiles(C) = 2 tiles — the per-tile branch of moe_mlp_tiles
+    must lay the shares out with THAT stride (C = 1 always takes it; C = 2 with the shared pass off).  shared_pass False: every candidate routes its own rows through the per-tile kernels — the SAME router
     kernel on the same fragments as the single verify, so no near-tie can flip.  True (the default from three tiles on):
     the 48 rows go through ONE pass over the experts (the prefill's grouped kernels); the router logits then come from the
     batch GEMM (another fp32 summation order), a near-tie at the k-th place may flip for a row, and the max bar is wider."""
@@ -284,15 +287,16 @@ def test_native_candidate_pass_on_moe_target_equals_single_verifies(shared_pass)
     g = torch.Generator().manual_seed(16)
     P, bs = 45, 16
     prompt = torch.randint(0, 2000, (1, P), generator=g).to(dev())
-    cands = torch.randint(0, 2000, (3, bs), generator=g).to(dev())
+    cands = torch.randint(0, 2000, (3, bs), generator=g).to(dev())[:C]
     cands[:, 0] = cands[0, 0]
     cache = nt.new_cache(160)
     nt.prefill(prompt, cache)
     taps = [0, 2]
     ver = NativeCandidateVerifier(nt, len(taps))
+    ver.part_h.fill_(float("nan"))      # stale shares must never be read
     post = ver.verify(cands, P, cache, taps).clone()
     assert cache.get_seq_length() == P
-    for c in range(3):
+    for c in range(C):
         c2 = nt.new_cache(160)
         nt.prefill(prompt, c2)
         logits = torch.zeros(32, 2048, dtype=BF16, device=dev())

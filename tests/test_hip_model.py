@@ -921,6 +921,61 @@ def test_graph_replayed_cycles_equal_eager_cycles():
     assert replayed >= 8, replayed      # most steady-state cycles really went through the graphs
 
 
+def test_captured_graphs_survive_a_replaced_rope_table():
+    """the captured launches hold raw pointers into the draft model's / target's RoPE tables, which
+    `_rope_tab` REPLACES when another caller on the same shared target needs more positions.  The session keeps the
+    captured tensors alive, notices the new table (`_graph_ok`), runs that cycle eagerly and captures again: ids and
+    acceptance lengths stay those of the eager loop."""
+    from dflash_amd import NativeTarget
+    from dflash_amd.generate import DecodeSession
+    from dflash_amd.synthetic import greedy_walk, impose_greedy_walk
+    cfg = H.tiny_cfg()
+    hf = _tiny_hf()
+    perm = impose_greedy_walk(hf, seed=8)
+    prompt = torch.randint(0, 2000, (1, 41), generator=torch.Generator().manual_seed(3)).to(dev())
+    n_new = 150
+    G = greedy_walk(perm, prompt, n_new + 60).to(dev())
+    plan = H.make_plan(64, 16, 29)
+
+    def hook(blk, start, call):
+        k = min(plan[call], blk.shape[1] - 1)
+        blk[0, 1:k + 1] = G[start + 1:start + k + 1]
+        if k + 1 < blk.shape[1]:
+            blk[0, k + 1] = (G[start + k + 1] + 1) % 2000
+
+    nt, m = NativeTarget(hf), make_model(cfg)
+    s = DecodeSession(m, nt, prompt, mask_token_id=cfg.mask_token_id, max_new_tokens=n_new, max_block_size=16,
+                      stop_token_ids=None, temperature=0.0, draft_token_hook=hook)
+    s.prefill()
+    taus, replayed, recaptured = [], 0, 0
+    for i in range(64):
+        if s.start >= s.max_length:
+            break
+        bs = min(16, s.max_length - s.start)
+        if i == 2:
+            s.capture(16)
+            old = (nt._rope[0], m._rope[0])
+        if i == 5:      # another caller needs a longer table: both owners allocate a new one, the old is released by them
+            need = 4 * nt._rope[0].shape[0]
+            nt._rope_tab(need)
+            m._rope_tab(need)
+            assert nt._rope[0].data_ptr() != old[0].data_ptr() and m._rope[0].data_ptr() != old[1].data_ptr()
+            del old
+            junk = [torch.full((1 << 16,), float("nan"), dtype=BF16, device=dev()) for _ in range(8)]   # reuse freed blocks
+        if i >= 2 and bs == 16:
+            if getattr(s, "_graph_bs", None) is None and s._ahead == 16:
+                s.capture(16)
+                recaptured += 1
+            replayed += int(s._graph_ok(16))
+            r = s.cycle_graph(16)
+        else:
+            r = s.cycle(bs, ahead_ok=bs == 16)
+        taus.append(r.tau)
+    assert s.finish()[0].tolist() == G[:41 + n_new].tolist()
+    assert recaptured == 1 and replayed >= 6, (recaptured, replayed)
+    del junk
+
+
 def test_generate_loop_with_graph_replay_env(monkeypatch):
     """DFL_GRAPH=1: dflash_generate replays its steady-state cycles from the captured graphs — same ids, same acceptance
     lengths as the eager loop (model/dflash.py:235-268 per cycle either way)."""
