@@ -26,7 +26,7 @@ from typing import Callable, Optional, Sequence
 import torch
 
 from . import ops
-from .generate import _bf16_table, _taps, _trim, cuda_time
+from .generate import _bf16_table, _taps, _trim, capture_graph, cuda_time
 from .model import DFlashDraftModel
 from .target import NativeTarget
 from .utils import sample
@@ -405,10 +405,7 @@ class BatchedDecoder:
         self.graphs = {}
         for name, fn in (("body", lambda: self._draft_body(kv)), ("head", self._draft_head),
                          ("verify", lambda: (self.verify(kv), self._accept_launch()))):
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                fn()
-            self.graphs[name] = g
+            self.graphs[name] = capture_graph(fn)   # (not torch.cuda.graph(): its empty_cache(), see generate.capture_graph)
 
     @torch.inference_mode()
     def cycle_graph(self, draft_token_hook: Optional[Callable] = None) -> list:

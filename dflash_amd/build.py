@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libdflash_hip.so")
 SOURCES = ["dfl_common.hip", "gemm_skinny.hip", "gemm_batch.hip", "rows.hip", "attn_block.hip", "attn_head.hip", "accept.hip", "candidates.hip", "moe.hip", "prefill.hip"]
-HEADERS = [os.path.join(CSRC, "dfl_common.h"), os.path.join(CSRC, "gemm_rows.h"), os.path.join(CSRC, "moe_route.h"),
+HEADERS = [os.path.join(CSRC, "dfl_common.h"), os.path.join(CSRC, "gemm_rows.h"), os.path.join(CSRC, "gemm_ring.h"), os.path.join(CSRC, "moe_route.h"),
            os.path.join(HERE, "..", "include", "dflash_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 

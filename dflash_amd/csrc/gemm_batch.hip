@@ -13,6 +13,8 @@
 // spinning, nothing to deadlock — sums them in a fixed order and runs the epilogue.
 // Request r reads its rows at base + r * stride and its lengths from dyn + 8 r.
 #include "gemm_rows.h"
+#include "gemm_ring.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -481,8 +483,50 @@ __global__ __launch_bounds__(256) void k_norm_frag_b(bf16_t *h, int64_t h_stride
 }
 
 constexpr int64_t WS_TICKETS = 1024;                                  // 256 ints
-constexpr int64_t WS_ARGMAX = 256 * 8 * 4 * 16 * (int64_t)(sizeof(float) + sizeof(int));  // [wg][wave][req][row]
+constexpr int64_t WS_CAND = 256 * 16 * 4 * 16;                         // argmax candidates [wg][wave <= 16][req][row]
+constexpr int64_t WS_ARGMAX = WS_CAND * (int64_t)(sizeof(float) + sizeof(int));
 constexpr int64_t WS_HEAD = WS_TICKETS + WS_ARGMAX;
+
+// DFL_BATCH_GEMM=slab: the round-1..3 form (k_gemm_b: K cut over workgroups, fp32 slabs + ticket) for every batched
+// GEMM — A/B measurement and the second implementation the tests compare with.  Default: the ring form (gemm_ring.h)
+// where it applies (gate/up, lm_head from fragment sources).
+bool use_ring() {
+  static const bool v = [] {
+    const char *e = getenv("DFL_BATCH_GEMM");
+    return !(e && e[0] == 's');
+  }();
+  return v;
+}
+
+// workgroups, units per workgroup and pass, passes: every workgroup walks ceil(nunits / gx) units in passes of <= upp_max
+void ring_plan(GemmRArgs &a, int nunits, int upp_max, int &gx) {
+  gx = nunits < 256 ? nunits : 256;
+  const int per_wg = (nunits + gx - 1) / gx;
+  a.nunits = nunits;
+  a.npass = (per_wg + upp_max - 1) / upp_max;
+  a.upp = (per_wg + a.npass - 1) / a.npass;
+}
+
+template <int MT, int TPU, int KQ, int NW, int A, int EPI>
+void launch_ring(const GemmRArgs &a, int gx, hipStream_t st) {
+  constexpr int lds = ring_lds_bytes<MT, TPU, KQ, NW, A>();
+  static bool attr_set = false;  // more than 64 KB of dynamic LDS needs the attribute (set once per instantiation)
+  void (*kern)(GemmRArgs) = dfl_k_gemm_r<MT, TPU, KQ, NW, A, EPI>;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(gx), dim3(NW * 64), lds, st, a);
+}
+
+void fill_ring(GemmRArgs &a, const void *wp, const dfl_rows_batch *x, int N, int K, const int32_t *dyn) {
+  a.wp = (const bf16x8 *)wp;
+  a.xf = (const bf16x8 *)x->r0.frag;
+  a.frag_stride8 = x->frag_stride / 8;
+  a.KS = K / 32;
+  a.ntiles = N / 16;
+  a.dyn = dyn;
+}
 
 int batch_ksplit(int K) { return (K / 32 + 63) / 64; }
 int mt_of(int R) { return R <= 2 ? 2 : 4; }
@@ -522,7 +566,7 @@ bool fill_batch(GemmBArgs &a, const void *wp, const dfl_rows_batch *x, int R, in
   if (ws) {
     a.tickets = (int *)ws;
     a.best_val = (float *)((char *)ws + WS_TICKETS);
-    a.best_idx = (int *)((char *)ws + WS_TICKETS + 256 * 8 * 4 * 16 * sizeof(float));
+    a.best_idx = (int *)((char *)ws + WS_TICKETS + WS_CAND * sizeof(float));
     a.part = (float *)((char *)ws + WS_HEAD);
     a.part_bytes = (int64_t)ksplit * a.ntiles * mt_of(R) * 256 * sizeof(float);
   }
@@ -566,6 +610,30 @@ extern "C" int dfl_gemm_silu_mul_batch(const void *wp_gateup, const dfl_rows_bat
   GemmBArgs a{};
   DFL_REQUIRE(act_frag && ws, "dfl_gemm_silu_mul_batch: null pointer");
   DFL_REQUIRE(act_stride >= 16 * (int64_t)I, "dfl_gemm_silu_mul_batch: act_stride < 16*I");
+  if (use_ring() && wp_gateup && ring_ok(x, K) && R >= 1 && R <= 4 && I > 0 && I % 16 == 0 && x->frag_stride % 8 == 0) {
+    // ring form: a wave owns a (gate, up) tile pair and a quarter of every K chunk; no K cut over workgroups
+    GemmRArgs r{};
+    fill_ring(r, wp_gateup, x, 2 * I, K, dyn);
+    r.act = (bf16_t *)act_frag;
+    r.act_stride = act_stride;
+    int gx = 0;
+    const int per_wg = (I / 16 + 255) / 256;
+    const bool w16 = per_wg % 4 == 0 || per_wg > 6;  // units per pass: 3 (12 waves) or 4 (16 waves)
+    ring_plan(r, I / 16, w16 ? 4 : 3, gx);
+    if (R <= 2) {
+      if (w16)
+        launch_ring<2, 2, 4, 16, 3, EPI_SILU>(r, gx, (hipStream_t)stream);
+      else
+        launch_ring<2, 2, 4, 12, 3, EPI_SILU>(r, gx, (hipStream_t)stream);
+    } else {
+      if (w16)
+        launch_ring<4, 2, 4, 16, 2, EPI_SILU>(r, gx, (hipStream_t)stream);
+      else
+        launch_ring<4, 2, 4, 12, 3, EPI_SILU>(r, gx, (hipStream_t)stream);
+    }
+    DFL_CHECK_LAUNCH("dfl_gemm_silu_mul_batch");
+    return DFL_OK;
+  }
   if (!fill_batch(a, wp_gateup, x, R, 2 * I, K, dyn, ws, "dfl_gemm_silu_mul_batch")) return DFL_EINVAL;
   a.act = (bf16_t *)act_frag;
   a.act_stride = act_stride;
@@ -606,6 +674,29 @@ extern "C" int dfl_gemm_argmax_batch(const void *wp, const dfl_rows_batch *x, in
   DFL_REQUIRE(ws && out_ids, "dfl_gemm_argmax_batch: null pointer");
   DFL_REQUIRE(row0 >= 0 && nrows >= 0 && row0 + nrows <= 16, "dfl_gemm_argmax_batch: rows [%d,%d) outside the tile", row0,
               row0 + nrows);
+  if (use_ring() && wp && ring_ok(x, K) && R >= 1 && R <= 4 && V > 0 && V % 16 == 0 && x->frag_stride % 8 == 0) {
+    // ring form: a wave owns a column tile over the whole K, the workgroup walks its tiles in passes of <= 16
+    GemmRArgs r{};
+    fill_ring(r, wp, x, V, K, dyn);
+    r.row0 = row0;
+    r.nrows = nrows;
+    r.nrows_word = nrows_dyn_word;
+    r.best_val = (float *)((char *)ws + WS_TICKETS);
+    r.best_idx = (int *)((char *)ws + WS_TICKETS + WS_CAND * sizeof(float));
+    r.logits = (bf16_t *)logits;
+    r.logits_stride = logits_stride;
+    r.N = V;
+    int gx = 0;
+    ring_plan(r, V / 16, 16, gx);
+    if (R <= 2)
+      launch_ring<2, 1, 1, 16, 2, EPI_ARGMAX>(r, gx, (hipStream_t)stream);
+    else
+      launch_ring<4, 1, 1, 16, 2, EPI_ARGMAX>(r, gx, (hipStream_t)stream);
+    hipLaunchKernelGGL(k_argmax_finish_b, dim3(16, R), dim3(64), 0, (hipStream_t)stream, r.best_val, r.best_idx, gx * 16,
+                       mt_of(R), row0, nrows, dyn, nrows_dyn_word, out_ids, out_stride, out_off);
+    DFL_CHECK_LAUNCH("dfl_gemm_argmax_batch");
+    return DFL_OK;
+  }
   if (!fill_batch(a, wp, x, R, V, K, dyn, ws, "dfl_gemm_argmax_batch")) return DFL_EINVAL;
   a.row0 = row0;
   a.nrows = nrows;

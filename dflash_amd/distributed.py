@@ -71,14 +71,15 @@ def merge_sharded(per_rank: list, n: int) -> list:
     return out
 
 
-def reduce_timing(seconds: float, units: float, device=None):
-    """(max seconds over ranks, total units): the bench's whole-job throughput inputs."""
+def reduce_timing(seconds: float, units: float, device=None, group=None):
+    """(max seconds over ranks, total units): the bench's whole-job throughput inputs.  group: the process group to
+    reduce over (bench.py: an RCCL group created only after the timed regions; default: the default group)."""
     if not dist.is_initialized():
         return seconds, units
-    if dist.get_backend() == "gloo":
-        device = None   # host tensors (CPU tests, one-GPU rehearsal)
+    if dist.get_backend(group) == "gloo":
+        device = None   # host tensors (CPU tests, one-GPU rehearsal, bench.py's default group)
     t = torch.tensor([seconds, units], dtype=torch.float64, device=device)
     mx, sm = t.clone(), t.clone()
-    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-    dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
+    dist.all_reduce(sm, op=dist.ReduceOp.SUM, group=group)
     return float(mx[0]), float(sm[1])

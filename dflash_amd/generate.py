@@ -35,6 +35,27 @@ def cuda_time() -> float:
     return time.perf_counter()
 
 
+def capture_graph(fn) -> "torch.cuda.CUDAGraph":
+    """Capture fn()'s launches into a hipGraph WITHOUT `torch.cuda.graph()`'s preamble.  That context manager calls
+    `torch.cuda.empty_cache()` before it begins a capture: every block in torch's caching allocator goes back to the
+    driver — with a NativeTarget(keep_hf=False) that is the ~17 GB of the wrapped model's dropped weights — and the driver
+    clears released VRAM in the background, on the GPU, for the next few hundred milliseconds.  Every kernel that runs
+    meanwhile is 2 - 4 % slower (measured, round 4: DESIGN.md section 5, profiles/r4_graph_ab.txt; rounds 2 - 3 read this
+    as "kernels are slower once a graph exists").  Nothing here needs the cache emptied: the launches allocate nothing."""
+    g = torch.cuda.CUDAGraph()
+    cur = torch.cuda.current_stream()
+    side = torch.cuda.Stream()
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        g.capture_begin()
+        try:
+            fn()
+        finally:
+            g.capture_end()
+    cur.wait_stream(side)
+    return g
+
+
 def _new_target_cache(target):
     if hasattr(target, "new_cache"):
         return target.new_cache()
@@ -376,10 +397,7 @@ class DecodeSession:
 
         self._graphs = {}
         for name, fn in (("verify", verify_accept), ("draft", draft_next)):
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                fn()
-            self._graphs[name] = g
+            self._graphs[name] = capture_graph(fn)
         self._graph_bs = bs
         # every tensor whose address sits in the captured launches and that this session does not own through another
         # attribute: the RoPE tables and the shared workspaces of the draft model and of the target

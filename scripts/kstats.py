@@ -8,7 +8,7 @@ if os.path.isdir(p):
 rows = list(csv.DictReader(open(p)))
 for r in rows:
     n = r["Name"]
-    if "k_" not in n or "anonymous" not in n:
+    if "k_" not in n or ("anonymous" not in n and "dfl_k_" not in n):
         continue
     n = re.sub(r"\(anonymous namespace\)::", "", n)
     n = re.sub(r"\(.*", "", n).replace("void ", "")

@@ -17,7 +17,7 @@ def nm(r):
 
 agg = collections.OrderedDict()
 for i, r in enumerate(rows):
-    if "anonymous namespace" not in r["Kernel_Name"] or "k_" not in r["Kernel_Name"]:
+    if ("anonymous namespace" not in r["Kernel_Name"] and "dfl_k_" not in r["Kernel_Name"]) or "k_" not in r["Kernel_Name"]:
         continue
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     gap = (int(rows[i + 1]["Start_Timestamp"]) - e) / 1e3 if i + 1 < len(rows) else 0.0

@@ -10,8 +10,9 @@ import csv, hashlib, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNEL_SOURCES = ["dflash_amd/csrc/gemm_skinny.hip", "dflash_amd/csrc/gemm_rows.h", "dflash_amd/csrc/dfl_common.h"]
 # --batch: the 4-request leg (bench.py --requests-per-gpu 4): the ragged-batch lm_head / gate-up kernels of gemm_batch.hip
-BATCH_SOURCES = ["dflash_amd/csrc/gemm_batch.hip", "dflash_amd/csrc/gemm_rows.h", "dflash_amd/csrc/dfl_common.h"]
-BATCH_KERNELS = {"lm_head": ("k_gemm_b<4,2>", 151936 * 4096 * 2), "gate_up": ("k_gemm_b<4,1>", 2 * 12288 * 4096 * 2)}
+BATCH_SOURCES = ["dflash_amd/csrc/gemm_batch.hip", "dflash_amd/csrc/gemm_ring.h", "dflash_amd/csrc/gemm_rows.h", "dflash_amd/csrc/dfl_common.h"]
+# (round 4: the ring form, gemm_ring.h: dfl_k_gemm_r<MT, TPU, KQ, NW, A, EPI>)
+BATCH_KERNELS = {"lm_head": ("dfl_k_gemm_r<4,1,1,16,2,2>", 151936 * 4096 * 2), "gate_up": ("dfl_k_gemm_r<4,2,4,12,3,1>", 2 * 12288 * 4096 * 2)}
 # (round 3 names: k_gemm<MT, CHUNKED, EPI, NORM>; the normalised-source instantiations are the ones the cycle runs)
 KERNELS = {"gate_up": ("k_gemm<1,false,1,true>", 2 * 12288 * 4096 * 2), "lm_head": ("k_gemm<1,false,2,true>", 151936 * 4096 * 2)}
 
@@ -48,7 +49,7 @@ if __name__ == "__main__":
         for r in csv.DictReader(open(sys.argv[3])):
             nm = r["Name"].replace(" ", "")
             for key, (kname, _) in KERNELS.items():
-                if "::" + kname + "(" in nm and key in out["kernels"]:
+                if ("::" + kname + "(" in nm or nm.startswith("void" + kname + "(") or nm.startswith(kname + "(")) and key in out["kernels"]:
                     out["kernels"][key]["rocprof_avg_us"] = float(r["AverageNs"]) / 1e3
                     out["kernels"][key]["rocprof_calls"] = int(r["Calls"])
     json.dump(out, open(sys.argv[2], "w"), indent=1)

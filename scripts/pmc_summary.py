@@ -19,7 +19,7 @@ def load(counter):
         if r["Counter_Name"] != counter:
             continue
         n = r["Kernel_Name"]
-        if "k_" not in n or "anonymous" not in n:
+        if "k_" not in n or ("anonymous" not in n and "dfl_k_" not in n):
             continue
         n = re.sub(r"\(anonymous namespace\)::", "", n)
         n = re.sub(r"\(.*", "", n).replace("void ", "")

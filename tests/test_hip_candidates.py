@@ -288,7 +288,7 @@ def test_native_candidate_pass_on_moe_target_equals_single_verifies(shared_pass,
     P, bs = 45, 16
     prompt = torch.randint(0, 2000, (1, P), generator=g).to(dev())
     cands = torch.randint(0, 2000, (3, bs), generator=g).to(dev())[:C]
-    cands[:, 0] = cands[0, 0]
+    cands[:, 0] = cands[0, 0].clone()
     cache = nt.new_cache(160)
     nt.prefill(prompt, cache)
     taps = [0, 2]
