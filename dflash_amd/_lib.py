@@ -66,6 +66,8 @@ SIGNATURES = {
                                   _p, _i, _p, _i64, _i64, _i, _p, _p, _i64, _i, _p]),
     "dfl_attn_head_batch": (_i, [_p, _i64, _i, _i, _i, _i, _i64, _i, _i, _p, _p, _f, _p, _p, _i, _p, _p, _i, _i64, _f, _i,
                                  _p, _i, _p, _i, _p, _i64, _p]),
+    "dfl_attn_head_batch_f32": (_i, [_p, _i, _i64, _i64, _i, _i, _i, _i, _i64, _i, _i, _p, _p, _f, _p, _p, _i, _p, _p, _i, _i64, _f,
+                                     _i, _p, _i, _p, _i, _p, _i64, _p]),
     "dfl_attn_head_batch_t": (_i, [_p, _i64, _i, _i, _i, _i, _i64, _i, _i, _p, _p, _f, _p, _p, _i, _p, _p, _i, _i64, _f, _i,
                                    _p, _i, _p, _i, _p, _i64, _i64, _i, _p]),
     "dfl_topk_rows": (_i, [_p, _i64, _i, _i, _i, _p, _p, _p, _p]),

@@ -126,6 +126,10 @@ class BatchedDecoder:
         self.aws_t = ops.attn_fused_batch_ws(MT, t.n_q, t.n_kv, max_splits, dev)
         # round 2: the attention stage on finished bf16 q/k/v rows (dfl_attn_head_batch); "fused" keeps the round-1 stage
         self.attn_impl = getattr(model, "attn_impl", "head")
+        # round 4: the q/k/v projection leaves fp32 K-part sums and the attention launch sums them while it loads its rows
+        # (dfl_attn_head_batch_f32) — blocks of <= 16 rows, <= 2 K parts (hidden <= 4096); DFL_QKV_PARTS=0: the round-3 form
+        # (finished bf16 rows: slabs + ticket + combine inside the GEMM), kept as the second implementation
+        self.qkv_parts = (os.environ.get("DFL_QKV_PARTS", "1") != "0" and tiles_per_request == 1 and ops.batch_ksplit(H) <= 2)
         self.hws_d = ops.attn_head_batch_ws(MT, c.num_attention_heads, max_splits, dev, q_tiles=TPR)
         self.hws_t = ops.attn_head_batch_ws(MT, t.n_q, max_splits, dev, q_tiles=TPR)
         if TPR == 2 and self.attn_impl != "head":
@@ -254,7 +258,16 @@ class BatchedDecoder:
         for i, lw in enumerate(L):
             ops.norm_frag_batch(d["h"], R, lw["ln1"], eps, d["xn"], dyn_t, ops.DYN_BS,
                                 part=d["part_h"] if pend else None, N=H, K=pend)
-            if self.attn_impl == "head":
+            if self.attn_impl == "head" and self.qkv_parts:
+                # q/k/v as fp32 K-part sums; the parts meet in the attention launch's row loads (round 4)
+                ops.gemm_f32_batch(lw["qkv"], s["xn"], R, self.nqkv_d, H, d["part_qkv"], dyn_t)
+                ops.attn_head_batch_f32(qkv_parts=d["part_qkv"], nparts=nsp, MT=MT, ld=self.nqkv_d, q_col=0, k_col=c.q_dim,
+                                        v_col=c.q_dim + c.kv_dim, R=RQ, n_q=c.num_attention_heads,
+                                        n_kv=c.num_key_value_heads, q_norm_w=lw["q_norm"], k_norm_w=lw["k_norm"],
+                                        eps=c.rms_norm_eps, cos_tab=cos, sin_tab=sin, kcache=self.dk, vcache=self.dv, layer=i,
+                                        scale=c.head_dim ** -0.5, causal=False, dyn=self.dyn_t, kv_len_max=kvmax,
+                                        ws=self.hws_d, max_splits=self.max_splits, out_frag=d["attn"])
+            elif self.attn_impl == "head":
                 ops.gemm_resid_batch(lw["qkv"], s["xn"], R, self.nqkv_d, H, d["xq"], add_residual=False, ws=self.gws,
                                      dyn=dyn_t)
                 ops.attn_head_batch(xq=d["xq"], q_col=0, k_col=c.q_dim, v_col=c.q_dim + c.kv_dim, R=RQ,
@@ -317,7 +330,14 @@ class BatchedDecoder:
             ops.norm_frag_batch(tt["h"], R, lw["ln1"], t.eps, tt["xn"], dyn_t, ops.DYN_BS,
                                 part=tt["part_h"] if pend else None, N=H, K=pend, tap=ptap, nsplit=self._pend_ns)
             spread(pdup)
-            if self.attn_impl == "head":
+            if self.attn_impl == "head" and self.qkv_parts:
+                ops.gemm_f32_batch(lw["qkv"], s["xn"], R, t.nqkv, H, tt["part_qkv"], dyn_t)
+                ops.attn_head_batch_f32(qkv_parts=tt["part_qkv"], nparts=nsp, MT=MT, ld=t.nqkv, q_col=0, k_col=t.q_dim,
+                                        v_col=t.q_dim + t.kv_dim, R=RQ, n_q=t.n_q, n_kv=t.n_kv, q_norm_w=lw["q_norm"],
+                                        k_norm_w=lw["k_norm"], eps=t.eps, cos_tab=cos, sin_tab=sin, kcache=self.tk,
+                                        vcache=self.tv, layer=i, scale=128 ** -0.5, causal=True, dyn=self.dyn_t,
+                                        kv_len_max=kvmax, ws=self.hws_t, max_splits=self.max_splits, out_frag=tt["attn"])
+            elif self.attn_impl == "head":
                 ops.gemm_resid_batch(lw["qkv"], s["xn"], R, t.nqkv, H, tt["xq"], add_residual=False, ws=self.gws,
                                      dyn=dyn_t)
                 ops.attn_head_batch(xq=tt["xq"], q_col=0, k_col=t.q_dim, v_col=t.q_dim + t.kv_dim, R=RQ, n_q=t.n_q,

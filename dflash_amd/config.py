@@ -59,6 +59,12 @@ class DFlashConfig:
         rope = get("rope_parameters") or {}
         theta = get("rope_theta") or (rope.get("rope_theta") if isinstance(rope, dict) else None) or 1e6
         heads = get("num_attention_heads")
+        # model/dflash.py:56,97: a layer whose layer_types entry is "sliding_attention" attends within config.sliding_window
+        # only.  The kernels attend over the whole cached prefix: such a draft is rejected here, before anything is built.
+        lt = get("layer_types") or ()
+        if any(t == "sliding_attention" for t in lt) and get("sliding_window"):
+            raise NotImplementedError("sliding-window attention drafts (layer_types 'sliding_attention') are not supported "
+                                      "by the HIP path")
         return cls(
             hidden_size=get("hidden_size"), num_hidden_layers=get("num_hidden_layers"),
             num_attention_heads=heads, num_key_value_heads=get("num_key_value_heads", heads),

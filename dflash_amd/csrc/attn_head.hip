@@ -68,6 +68,14 @@ struct HeadAttnArgs {
   // own length record (dyn + c * dyn_cand_stride ints) and its own cache (+ c * cache_cand_stride elements).
   int64_t xq_cand_stride, out_cand_stride, ws_cand_stride, cache_cand_stride;
   int dyn_cand_stride;
+  // XF32 instantiations (round 4: dfl_attn_head_batch_f32): the block rows arrive as the fp32 K-PART SUMS of the qkv GEMM
+  // (dfl_gemm_f32_batch: [part][tile rows][ldq]) instead of finished bf16 rows; a row value is bf16(part 0 + part 1) —
+  // the Linear's bf16 output, summed in the order the GEMM's own combine used.  The K parts of q/k/v then meet HERE (these
+  // loads are a few KB per workgroup) and the qkv launch carries no slabs, ticket or combine phase (18.3 -> 14.7 us at 4
+  // tiles).  ldq / the column offsets / xq_cand_stride count floats of one part.
+  const float *xq32;
+  int64_t part_stride32;  // floats between the parts
+  int nparts32;           // 1 or 2
   bf16_t *k_out, *v_out;   // null: the new rows go to the cache at rows S + rel
   int64_t kv_out_cand_stride;
   int out_rows;
@@ -110,6 +118,7 @@ __device__ __forceinline__ float wave_g_sum(float v) {
 template <int NP>
 struct RopeLoads {
   bf16x8 xv[NP], cs[NP], sn[NP], wv;
+  f32x4 pa[NP][2], pb[NP][2];  // XF32: the item's 8 values of K part 0 / part 1 (untouched, i.e. optimised away, otherwise)
 };
 
 // issue: the loads only (row values, cos/sin rows, norm weight).  A wave's vector loads return in issue
@@ -129,6 +138,40 @@ __device__ __forceinline__ void rope_issue(const bf16_t *const (&src)[NP], const
   }
   // unconditional (a load under a branch makes hipcc wait vmcnt(0) at the join): no norm -> 16 B nobody uses
   ld.wv = *reinterpret_cast<const bf16x8 *>((nw ? nw : safe) + d0);
+}
+
+// XF32: the same requests for items given as fp32 K-part sums (src[p]: part 0; part 1 at + part_stride; nparts 1: part 1
+// is a second read of part 0 that the finish ignores — no load under a branch).  rope_sum32 turns them into the bf16
+// Linear outputs rope_finish expects.
+template <int NP>
+__device__ __forceinline__ void rope_issue32(const float *const (&src)[NP], const int (&pos)[NP], const bf16_t *nw,
+                                             const bf16_t *cos_tab, const bf16_t *sin_tab, int max_pos, const float *safe32,
+                                             const bf16_t *safe, int64_t part_stride, int nparts, int l, RopeLoads<NP> &ld) {
+  const int d0 = (l & 15) * 8;
+  const int64_t ps = nparts > 1 ? part_stride : 0;
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const float *b = (src[p] ? src[p] : safe32) + d0;
+    ld.pa[p][0] = *reinterpret_cast<const f32x4 *>(b);
+    ld.pa[p][1] = *reinterpret_cast<const f32x4 *>(b + 4);
+    ld.pb[p][0] = *reinterpret_cast<const f32x4 *>(b + ps);
+    ld.pb[p][1] = *reinterpret_cast<const f32x4 *>(b + ps + 4);
+    int pp = pos[p] < max_pos ? pos[p] : max_pos - 1;
+    pp = pp < 0 ? 0 : pp;
+    ld.cs[p] = *reinterpret_cast<const bf16x8 *>(cos_tab + (int64_t)pp * 64 + (d0 & 63));
+    ld.sn[p] = *reinterpret_cast<const bf16x8 *>(sin_tab + (int64_t)pp * 64 + (d0 & 63));
+  }
+  ld.wv = *reinterpret_cast<const bf16x8 *>((nw ? nw : safe) + d0);
+}
+template <int NP>
+__device__ __forceinline__ void rope_sum32(RopeLoads<NP> &ld, int nparts) {
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float s0 = ld.pa[p][j >> 2][j & 3], s1 = ld.pb[p][j >> 2][j & 3];
+      ld.xv[p][j] = f2bf(nparts > 1 ? s0 + s1 : s0);  // fixed part order, one rounding: the Linear's bf16 output
+    }
 }
 
 template <int NP>
@@ -229,7 +272,7 @@ struct HeadLds {
 // ~5k keys): the G heads of a kv group otherwise pull the same K/V through their XCD's L2 G times (S = 8192: 134 MB of
 // L2 reads per launch for 33.5 MB of cache, PMC: HBM fetch 34 MB), and with half the workgroups per split there are
 // twice the splits.
-template <int QT, int NW, bool SIGNAL, bool HP = false>
+template <int QT, int NW, bool SIGNAL, bool HP = false, bool XF32 = false>
 __device__ __forceinline__ void attn_head_body(const HeadAttnArgs &a, char *lds, int *s_last_p, const int kvh, const int by,
                                                const int cand, int *done_ctr) {
   static_assert(!HP || QT == 2, "head pairs use the two-tile register layout");
@@ -255,7 +298,8 @@ __device__ __forceinline__ void attn_head_body(const HeadAttnArgs &a, char *lds,
   const int qi = l & 15, g = l >> 4;
   HSTAMP(0);
   // per-candidate / per-request views as plain locals: the argument block stays untouched
-  const bf16_t *const xq = a.xq + cand * a.xq_cand_stride;
+  const bf16_t *const xq = XF32 ? a.cos_tab : a.xq + cand * a.xq_cand_stride;  // (XF32: only the dummy loads' safe address)
+  const float *const xq32 = XF32 ? a.xq32 + cand * a.xq_cand_stride : nullptr;
   bf16x8 *const out_frag = a.out_frag + cand * a.out_cand_stride;
   float *const o_part = a.o_part + cand * a.ws_cand_stride;
   float *const ml_part = a.ml_part + cand * a.ws_cand_stride;
@@ -316,9 +360,14 @@ __device__ __forceinline__ void attn_head_body(const HeadAttnArgs &a, char *lds,
   const int jhead = HP ? head + (jq >> 4) : head;  // ... and query head
   RopeLoads<1> qld;
   {
-    const bf16_t *src[1] = {jrow < bs ? xq + (int64_t)jrow * a.ldq + a.q_col + jhead * 128 : nullptr};
     const int pos[1] = {pos0 + tau + jrow};
-    rope_issue<1>(src, pos, a.q_w, a.cos_tab, a.sin_tab, a.max_pos, xq, l, qld);
+    if constexpr (XF32) {
+      const float *src[1] = {jrow < bs ? xq32 + (int64_t)jrow * a.ldq + a.q_col + jhead * 128 : nullptr};
+      rope_issue32<1>(src, pos, a.q_w, a.cos_tab, a.sin_tab, a.max_pos, xq32, xq, a.part_stride32, a.nparts32, l, qld);
+    } else {
+      const bf16_t *src[1] = {jrow < bs ? xq + (int64_t)jrow * a.ldq + a.q_col + jhead * 128 : nullptr};
+      rope_issue<1>(src, pos, a.q_w, a.cos_tab, a.sin_tab, a.max_pos, xq, l, qld);
+    }
   }
   // (compiler fences: without them hipcc hoists the K/V burst above the q loads and sinks the norm-weight load
   // into a branch of the arithmetic, and the q rows wait for the whole burst after all)
@@ -327,6 +376,7 @@ __device__ __forceinline__ void attn_head_body(const HeadAttnArgs &a, char *lds,
     if (jq < QT * 16) {
       const bool rp[1] = {true};
       bf16x8 ov[1];
+      if constexpr (XF32) rope_sum32<1>(qld, a.nparts32);
       rope_finish<1>(qld, rp, a.q_w != nullptr, a.eps, l, ov);
       const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
       *reinterpret_cast<bf16x8 *>(q_lds + (jq >> 4) * 4096 + k_swz(jq & 15, qi)) = jrow < bs ? ov[0] : z;
@@ -347,6 +397,7 @@ __device__ __forceinline__ void attn_head_body(const HeadAttnArgs &a, char *lds,
     auto sweep = [&](auto np_tag) {
       constexpr int NP = decltype(np_tag)::value;
       const bf16_t *src[NP];
+      const float *src32[NP];
       int pos[NP], rel[NP];
       bool rp[NP], isv[NP];
       bf16x8 ov[NP];
@@ -359,16 +410,26 @@ __device__ __forceinline__ void attn_head_body(const HeadAttnArgs &a, char *lds,
         // (arithmetic, not a select between two argument FIELDS: hipcc turns such a select into a select of their
         // addresses plus a per-lane global load with vmcnt(0) — four dependent round trips in this prologue)
         const int vsel = isv[p] ? 1 : 0;
-        const bf16_t *row = rel[p] < tau ? a.xc + (int64_t)rel[p] * a.ldc + a.ck_col + vsel * (a.cv_col - a.ck_col)
-                                         : xq + (int64_t)(rel[p] - tau) * a.ldq + a.k_col + vsel * (a.v_col - a.k_col);
-        src[p] = ok ? row + kvh * 128 : nullptr;
+        if constexpr (XF32) {  // (no context rows in this form: the host admits tau == 0 only)
+          src32[p] = ok ? xq32 + (int64_t)rel[p] * a.ldq + a.k_col + vsel * (a.v_col - a.k_col) + kvh * 128 : nullptr;
+          src[p] = ok ? xq : nullptr;   // presence flag for the stores below
+        } else {
+          const bf16_t *row = rel[p] < tau ? a.xc + (int64_t)rel[p] * a.ldc + a.ck_col + vsel * (a.cv_col - a.ck_col)
+                                           : xq + (int64_t)(rel[p] - tau) * a.ldq + a.k_col + vsel * (a.v_col - a.k_col);
+          src[p] = ok ? row + kvh * 128 : nullptr;
+          src32[p] = nullptr;
+        }
         pos[p] = pos0 + rel[p];
         rp[p] = !isv[p];
       }
       RopeLoads<NP> kld;
-      rope_issue<NP>(src, pos, a.k_w, a.cos_tab, a.sin_tab, a.max_pos, xq, l, kld);
+      if constexpr (XF32)
+        rope_issue32<NP>(src32, pos, a.k_w, a.cos_tab, a.sin_tab, a.max_pos, xq32, xq, a.part_stride32, a.nparts32, l, kld);
+      else
+        rope_issue<NP>(src, pos, a.k_w, a.cos_tab, a.sin_tab, a.max_pos, xq, l, kld);
       asm volatile("" ::: "memory");
       finish_q();
+      if constexpr (XF32) rope_sum32<NP>(kld, a.nparts32);
       rope_finish<NP>(kld, rp, a.k_w != nullptr, a.eps, l, ov);
 #pragma unroll
       for (int p = 0; p < NP; ++p)
@@ -706,6 +767,18 @@ __global__ __launch_bounds__(512) void k_attn_head_pair(HeadAttnArgs a) {  // tw
   attn_head_body<2, 8, false, true>(a, lds, &s_last, blockIdx.x, blockIdx.y, blockIdx.z, nullptr);
 }
 
+// the same two kernels on fp32 K-part sums of the qkv GEMM (HeadAttnArgs::xq32)
+__global__ __launch_bounds__(512) void k_attn_head32(HeadAttnArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds[HeadLds<1, 8>::kBytes];
+  __shared__ int s_last;
+  attn_head_body<1, 8, false, false, true>(a, lds, &s_last, blockIdx.x, blockIdx.y, blockIdx.z, nullptr);
+}
+__global__ __launch_bounds__(512) void k_attn_head_pair32(HeadAttnArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds[HeadLds<2, 8>::kBytes];
+  __shared__ int s_last;
+  attn_head_body<2, 8, false, true, true>(a, lds, &s_last, blockIdx.x, blockIdx.y, blockIdx.z, nullptr);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Attention stage + o_proj in ONE launch (round 2; VERDICT r1 item 4: a stage pair kept inside a launch where the
 // hand-off buys more than the boundary it replaces).  The attention stage leaves HBM idle for ~10 us per layer, and
@@ -875,8 +948,12 @@ int attn_head_launch(const void *xq, int64_t ldq, int q_col, int k_col, int v_co
                      float scale, int causal, const int32_t *dyn, int S, int tau, int bs, int pos0, int q_tiles, void *ws,
                      int max_splits, void *out_frag, int64_t out_tile_stride, int n_cand, int64_t xq_cand_stride,
                      int64_t out_cand_stride, void *k_out, void *v_out, int64_t kv_out_cand_stride, int out_rows,
-                     int dyn_cand_stride, int64_t cache_cand_stride, void *stream, const OprojTail *tail = nullptr) {
+                     int dyn_cand_stride, int64_t cache_cand_stride, void *stream, const OprojTail *tail = nullptr,
+                     int nparts32 = 0, int64_t part_stride32 = 0) {
+  // nparts32 > 0: xq points at fp32 K-part sums (HeadAttnArgs::xq32; strides in floats)
   DFL_REQUIRE(xq && cos_tab && sin_tab && kcache && vcache && out_frag && ws, "dfl_attn_head: null pointer");
+  DFL_REQUIRE(nparts32 >= 0 && nparts32 <= 2 && (nparts32 == 0 || (!tail && q_tiles == 1 && tau == 0 && !xc && part_stride32 % 4 == 0)),
+              "dfl_attn_head: the fp32-partials form takes 1 or 2 K parts, one query tile, no context rows");
   DFL_REQUIRE((q_norm_w == nullptr) == (k_norm_w == nullptr), "dfl_attn_head: give both norm weights or neither");
   DFL_REQUIRE(n_q > 0 && n_kv > 0 && n_q % n_kv == 0, "dfl_attn_head: bad head counts (n_q=%d n_kv=%d)", n_q, n_kv);
   DFL_REQUIRE(q_tiles == 1 || q_tiles == 2, "dfl_attn_head: q_tiles must be 1 or 2");
@@ -982,6 +1059,18 @@ int attn_head_launch(const void *xq, int64_t ldq, int q_col, int k_col, int v_co
   a.cache_cand_stride = cache_cand_stride;
   const dim3 grid(n_kv, (pair ? G / 2 : G) * (ns_old + 1), n_cand);
   hipStream_t st = (hipStream_t)stream;
+  if (nparts32 > 0) {
+    a.xq = nullptr;
+    a.xq32 = (const float *)xq;
+    a.nparts32 = nparts32;
+    a.part_stride32 = part_stride32;
+    if (pair)
+      hipLaunchKernelGGL(k_attn_head_pair32, grid, dim3(512), 0, st, a);
+    else
+      hipLaunchKernelGGL(k_attn_head32, grid, dim3(512), 0, st, a);
+    DFL_CHECK_LAUNCH("dfl_attn_head_batch_f32");
+    return DFL_OK;
+  }
   if (pair) {
     hipLaunchKernelGGL(k_attn_head_pair, grid, dim3(512), 0, st, a);
     DFL_CHECK_LAUNCH("dfl_attn_head");
@@ -1101,3 +1190,22 @@ extern "C" int dfl_attn_head_cand_t(const void *xq, int64_t ldq, int q_col, int 
                           v_out, kv_out_cand_stride, out_rows, 0, 0, stream);
 }
 
+// dfl_attn_head_batch on the fp32 K-PART SUMS of the qkv projection (dfl_gemm_f32_batch's output: [part][R tiles x 16
+// rows][ldq] floats) instead of finished bf16 rows: request r's rows of part k at xq_parts + k * part_stride +
+// r * xq_req_stride (floats); a value is bf16(part 0 + part 1).  The K parts of the projection meet in this launch's row
+// loads, so the GEMM in front of it needs no slab / ticket / combine phase of its own.
+extern "C" int dfl_attn_head_batch_f32(const float *xq_parts, int nparts, int64_t part_stride, int64_t ldq, int q_col, int k_col,
+                                       int v_col, int R, int64_t xq_req_stride, int n_q, int n_kv, const void *q_norm_w,
+                                       const void *k_norm_w, float eps, const void *cos_tab, const void *sin_tab, int max_pos,
+                                       void *kcache, void *vcache, int cache_rows, int64_t cache_req_stride, float scale,
+                                       int causal, const int32_t *dyn, int kv_len_max, void *ws, int max_splits,
+                                       void *out_frag, int64_t out_req_stride, void *stream) {
+  DFL_REQUIRE(dyn, "dfl_attn_head_batch_f32: the requests' lengths come from dyn (R records)");
+  DFL_REQUIRE(nparts == 1 || nparts == 2, "dfl_attn_head_batch_f32: 1 or 2 K parts (got %d)", nparts);
+  DFL_REQUIRE(kv_len_max >= 16 && kv_len_max <= cache_rows, "dfl_attn_head_batch_f32: kv_len_max=%d outside 16..cache_rows",
+              kv_len_max);
+  return attn_head_launch(xq_parts, ldq, q_col, k_col, v_col, nullptr, 0, 0, 0, n_q, n_kv, q_norm_w, k_norm_w, eps, cos_tab,
+                          sin_tab, max_pos, kcache, vcache, cache_rows, scale, causal, dyn, kv_len_max - 16, 0, 16, 0, 1, ws,
+                          max_splits, out_frag, 0, R, xq_req_stride, out_req_stride, nullptr, nullptr, 0, 0, DFL_DYN_WORDS,
+                          cache_req_stride, stream, nullptr, nparts, part_stride);
+}

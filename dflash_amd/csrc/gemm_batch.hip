@@ -269,11 +269,7 @@ __global__ __launch_bounds__(512) void k_gemm_b(GemmBArgs a) {
     if (tid == 0) {
       const int ticket = __hip_atomic_fetch_add(&a.tickets[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int last = ticket == nky - 1;
-      if (last) {
-        __hip_atomic_store(&a.tickets[blockIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // this CU's L1 may hold stale slab lines
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
+      if (last) __hip_atomic_store(&a.tickets[blockIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
       s_last = last;
     }
     __syncthreads();
@@ -282,9 +278,11 @@ __global__ __launch_bounds__(512) void k_gemm_b(GemmBArgs a) {
     // (Tried: batches sized to the wave's item count and two K parts per round — slower, 16.8 ->
     // 19.5 us on o_proj at 4 tiles; the simple form stays.)
     constexpr int UB = 8;
+    // Hand-off of the slabs (MI355X_MICROARCH.md, "Valid forms", table row 1): every slab byte was stored sc1 (write-
+    // through), every storing wave drained (vmcnt(0)) before the workgroup barrier in front of its ONE ticket add, the
+    // consumer's waves load behind the barrier that follows the returned add — and EVERY load of the handed-off bytes
+    // is an sc1 load (L1 bypassed), so no agent-scope acquire (buffer_inv sc1: ~1.7 us per launch, rounds 1-3) is needed.
     const int nitems = (nseq / TPU) * MT;
-    const float *pbase = a.part + 4 * l;
-    const size_t kstride = (size_t)a.ntiles * MT * 256;
     for (int it0 = w; it0 < nitems; it0 += NW * UB) {
       f32x4 sv[UB][TPU];
 #pragma unroll
@@ -298,9 +296,9 @@ __global__ __launch_bounds__(512) void k_gemm_b(GemmBArgs a) {
           it = it < nitems ? it : nitems - 1;
           const int u = it / MT, mt = it - u * MT;
 #pragma unroll
-          for (int tp = 0; tp < TPU; ++tp)
-            sv[b][tp] += *reinterpret_cast<const f32x4 *>(pbase + k * kstride +
-                                                          ((size_t)tile_of(u * TPU + tp) * MT + mt) * 256);
+          for (int tp = 0; tp < TPU; ++tp)  // sc1 loads (L2-served): see the hand-off note above the combine
+            sv[b][tp] += __builtin_bit_cast(
+                f32x4, __builtin_amdgcn_raw_buffer_load_b128(part_rsrc, slab_off(k, tile_of(u * TPU + tp), mt), 0, 16));
         }
       }
 #pragma unroll
@@ -507,19 +505,41 @@ void ring_plan(GemmRArgs &a, int nunits, int upp_max, int &gx) {
   a.upp = (per_wg + a.npass - 1) / a.npass;
 }
 
-template <int MT, int TPU, int KQ, int NW, int A, int EPI>
-void launch_ring(const GemmRArgs &a, int gx, hipStream_t st) {
-  constexpr int lds = ring_lds_bytes<MT, TPU, KQ, NW, A>();
+template <int MT, int TPU, int KQ, int NW, int A, int EPI, int CK = 8>
+void launch_ring(const GemmRArgs &a, int gx, hipStream_t st, int gy = 1) {
+  constexpr int lds = ring_lds_bytes<MT, TPU, KQ, NW, A, CK>();
   static bool attr_set = false;  // more than 64 KB of dynamic LDS needs the attribute (set once per instantiation)
-  void (*kern)(GemmRArgs) = dfl_k_gemm_r<MT, TPU, KQ, NW, A, EPI>;
+  void (*kern)(GemmRArgs) = dfl_k_gemm_r<MT, TPU, KQ, NW, A, EPI, CK>;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(gx), dim3(NW * 64), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(NW * 64), lds, st, a);
+}
+
+// DFL_RING_VARIANT=<n>: A/B knob for the lm_head launch (0: 8-k-step slots, two chunks ahead; 1: 16-k-step slots, one ahead)
+int ring_variant() {
+  static const int v = [] {
+    const char *e = getenv("DFL_RING_VARIANT");
+    return e ? atoi(e) : 0;
+  }();
+  return v;
+}
+
+// DFL_RING_ROT=m: workgroup b starts its K walk at chunk (b * m) % chunks.  Default 0 (every workgroup at chunk 0):
+// measured on one box, 4 tiles, gate/up 37.3 us at m = 0 against 39.8 / 38.9 / 39.5 at m = 1 / 3 / 5, lm_head 221 - 222 us
+// either way (profiles/r4_ring_microbench.txt) — HBM channel camping is not what limits the walk, and workgroups in
+// step share each activation chunk's L2 lines.
+int ring_rot() {
+  static const int v = [] {
+    const char *e = getenv("DFL_RING_ROT");
+    return e ? atoi(e) : 0;
+  }();
+  return v;
 }
 
 void fill_ring(GemmRArgs &a, const void *wp, const dfl_rows_batch *x, int N, int K, const int32_t *dyn) {
+  a.rot_mul = ring_rot();
   a.wp = (const bf16x8 *)wp;
   a.xf = (const bf16x8 *)x->r0.frag;
   a.frag_stride8 = x->frag_stride / 8;
@@ -595,6 +615,36 @@ extern "C" int dfl_gemm_f32_batch(const void *wp, const dfl_rows_batch *x, int R
                                   const int32_t *dyn, void *stream) {
   GemmBArgs a{};
   DFL_REQUIRE(out, "dfl_gemm_f32_batch: null pointer");
+  // Ring form with K cut over grid.y (round 4, DFL_RING_F32=1; OFF by default): the same part count and output layout as
+  // k_gemm_b (the consumer adds dfl_batch_ksplit(K) parts), but a workgroup's 2048-wide K part of the activations streams
+  // through the LDS ring instead of being loaded into registers in front of the first MFMA.  Applies where a workgroup
+  // holds >= 6 tiles of a part (bytes in flight = tiles x look-ahead): down_proj (7 tiles x 6 parts).  MEASURED SLOWER
+  // there than the register-resident form: 23.8 against 22.7 us per launch, 5.25 against 5.11 ms per 4-request cycle
+  // (profiles/r4_batch4_ab.txt) — with a 2048-wide K part resident in registers the workgroup has ALL its activations
+  // after one burst and 3 x 64 KB weight items in flight; the ring holds 24 k-steps of look-ahead.  Kept as the measured
+  // variant; o_proj in four K parts on the same form was tried as well (12.0 against 11.9 us, and the norm launch
+  // behind it reads four parts: 5.23 against 5.16 ms) and removed.
+  static const int ring_f32 = [] { const char *e = getenv("DFL_RING_F32"); return e ? atoi(e) : 0; }();
+  {
+    const int ksplit = batch_ksplit(K), nt = N / 16;
+    const int gxm = 256 / ksplit > 0 ? 256 / ksplit : 1;
+    const int U = (nt + gxm - 1) / gxm;   // tiles per workgroup and part
+    if (ring_f32 && use_ring() && wp && ring_ok(x, K) && R >= 3 && R <= 4 && N % 16 == 0 && x->frag_stride % 8 == 0 && U >= 6 &&
+        U <= 8 && ksplit >= 2) {
+      GemmRArgs r{};
+      fill_ring(r, wp, x, N, K, dyn);
+      r.out = out;
+      r.ldo = N;
+      r.ksp = 8 * ((K / 32 + 8 * ksplit - 1) / (8 * ksplit));   // the k-steps of k_gemm_b's parts: 8 waves x nfr
+      r.nunits = nt;
+      r.npass = 1;
+      r.upp = U;
+      const int gx = (nt + U - 1) / U;
+      launch_ring<4, 1, 2, 16, 3, EPI_F32>(r, gx, (hipStream_t)stream, ksplit);
+      DFL_CHECK_LAUNCH("dfl_gemm_f32_batch");
+      return DFL_OK;
+    }
+  }
   if (!fill_batch(a, wp, x, R, N, K, dyn, nullptr, "dfl_gemm_f32_batch")) return DFL_EINVAL;
   a.out = out;
   a.ldo = N;
@@ -628,8 +678,12 @@ extern "C" int dfl_gemm_silu_mul_batch(const void *wp_gateup, const dfl_rows_bat
     } else {
       if (w16)
         launch_ring<4, 2, 4, 16, 2, EPI_SILU>(r, gx, (hipStream_t)stream);
-      else
+      else if (ring_variant() & 2)   // A/B: four chunks ahead (160 KB of ring)
+        launch_ring<4, 2, 4, 12, 4, EPI_SILU>(r, gx, (hipStream_t)stream);
+      else if (ring_variant() & 4)   // A/B: three chunks ahead
         launch_ring<4, 2, 4, 12, 3, EPI_SILU>(r, gx, (hipStream_t)stream);
+      else   // two chunks ahead (16 chunks at K = 4096: no padding iterations): in the cycle 35.0 us against 37.3 (three)
+        launch_ring<4, 2, 4, 12, 2, EPI_SILU>(r, gx, (hipStream_t)stream);
     }
     DFL_CHECK_LAUNCH("dfl_gemm_silu_mul_batch");
     return DFL_OK;
@@ -650,6 +704,35 @@ extern "C" int dfl_gemm_resid_batch(const void *wp, const dfl_rows_batch *x, int
   GemmBArgs a{};
   DFL_REQUIRE(h_io && ws, "dfl_gemm_resid_batch: null pointer");
   DFL_REQUIRE(ldh >= N && (!tap || ldtap >= N), "dfl_gemm_resid_batch: row strides shorter than N");
+  // DFL_RING_RESID=1|2 (A/B knob, default off): the ring form for the small-N projections too — finished sums, no K cut.
+  // What bounds it there is the ring itself: bytes of weights in flight = tiles per workgroup x look-ahead k-steps, and the
+  // look-ahead is capped by LDS (4 KiB of activations per k-step at 4 tiles): DESIGN.md section 6b.
+  static const int ring_resid = [] { const char *e = getenv("DFL_RING_RESID"); return e ? atoi(e) : 0; }();
+  if (ring_resid && use_ring() && wp && ring_ok(x, K) && R >= 3 && R <= 4 && !ss_out && N % 16 == 0 && K <= 4096 &&
+      x->frag_stride % 8 == 0) {
+    GemmRArgs r{};
+    fill_ring(r, wp, x, N, K, dyn);
+    r.h_io = (bf16_t *)h_io;
+    r.ldh = ldh;
+    r.h_stride = h_stride;
+    r.add_resid = add_residual ? 1 : 0;
+    r.tap = (bf16_t *)tap;
+    r.ldtap = ldtap;
+    r.tap_stride = tap_stride;
+    r.nunits = N / 16;
+    r.npass = 1;
+    if (ring_resid == 1) {  // 3 tiles per workgroup, 4 waves per tile
+      r.upp = 3;
+      const int gx = (r.nunits + 2) / 3;
+      launch_ring<4, 1, 4, 12, 4, EPI_RESID>(r, gx, (hipStream_t)stream);
+    } else {                // 2 tiles per workgroup, 8 waves per tile
+      r.upp = 2;
+      const int gx = (r.nunits + 1) / 2;
+      launch_ring<4, 1, 8, 16, 4, EPI_RESID>(r, gx, (hipStream_t)stream);
+    }
+    DFL_CHECK_LAUNCH("dfl_gemm_resid_batch");
+    return DFL_OK;
+  }
   if (!fill_batch(a, wp, x, R, N, K, dyn, ws, "dfl_gemm_resid_batch")) return DFL_EINVAL;
   a.h_io = (bf16_t *)h_io;
   a.ldh = ldh;
@@ -690,9 +773,11 @@ extern "C" int dfl_gemm_argmax_batch(const void *wp, const dfl_rows_batch *x, in
     ring_plan(r, V / 16, 16, gx);
     if (R <= 2)
       launch_ring<2, 1, 1, 16, 2, EPI_ARGMAX>(r, gx, (hipStream_t)stream);
+    else if (ring_variant() & 1)
+      launch_ring<4, 1, 1, 16, 1, EPI_ARGMAX, 16>(r, gx, (hipStream_t)stream);
     else
       launch_ring<4, 1, 1, 16, 2, EPI_ARGMAX>(r, gx, (hipStream_t)stream);
-    hipLaunchKernelGGL(k_argmax_finish_b, dim3(16, R), dim3(64), 0, (hipStream_t)stream, r.best_val, r.best_idx, gx * 16,
+    hipLaunchKernelGGL(k_argmax_finish_b, dim3(16, R), dim3(64), 0, (hipStream_t)stream, r.best_val, r.best_idx, gx,
                        mt_of(R), row0, nrows, dyn, nrows_dyn_word, out_ids, out_stride, out_off);
     DFL_CHECK_LAUNCH("dfl_gemm_argmax_batch");
     return DFL_OK;

@@ -43,7 +43,7 @@ struct GemmRArgs {
   int64_t act_stride;
   // EPI_ARGMAX
   int row0, nrows, nrows_word;
-  float *best_val;  // [gridDim.x * NW][MT][16]
+  float *best_val;  // [gridDim.x][MT][16]
   int *best_idx;
   bf16_t *logits;  // optional [16][N] per request
   int64_t logits_stride;
@@ -51,6 +51,16 @@ struct GemmRArgs {
   // EPI_F32: out[(mt * 16 + m) * ldo + n]
   float *out;
   int ldo;
+  int rot_mul;  // workgroup b starts its K walk at chunk (b * rot_mul) % chunks (0: every workgroup at chunk 0)
+  int ksp;      // EPI_F32 with K cut over grid.y (0: no cut): k-steps per K part; part y writes out + y * MT * 16 * ldo
+  // EPI_RESID: h[r][m][n] <- bf16(sum) or bf16(h + bf16(sum)) (model/dflash.py:140,144), optional second copy (tap)
+  bf16_t *h_io;
+  int64_t ldh, h_stride;
+  int add_resid;
+  bf16_t *tap;
+  int64_t ldtap, tap_stride;
+  float *ss_out;  // optional [ntiles][16] per request: sum over the tile's 16 columns of the new rows' squares (next RMSNorm)
+  int64_t ss_stride;
 };
 
 namespace {
@@ -62,10 +72,10 @@ constexpr int R_CK = 8;  // k-steps per ring slot
 
 // MT request tiles, TPU tiles per unit, KQ waves per unit (each takes CK / KQ k-steps of every chunk), NW waves per
 // workgroup, A chunks of look-ahead (weights in flight per wave: A * CK / KQ * TPU KiB; ring: A + 1 slots)
-template <int MT, int TPU, int KQ, int NW, int A, int EPI>
+template <int MT, int TPU, int KQ, int NW, int A, int EPI, int CK = 8>
 __global__ __launch_bounds__(NW * 64) void dfl_k_gemm_r(GemmRArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass needs the kernel's handle only; with this body it drops the instantiation (no diagnostic)
-  constexpr int CK = R_CK, KPC = CK / KQ, NS = A + 1;
+  constexpr int KPC = CK / KQ, NS = A + 1;  // CK: k-steps per ring slot
   constexpr int NPIECE = CK * MT;                 // 1 KiB pieces per chunk
   constexpr int SP = (NPIECE + NW - 1) / NW;      // pieces per wave and chunk (surplus: a duplicate of the last piece)
   constexpr int VMC = A * KPC * TPU + (A - 1) * SP;  // VMEM ops of a wave younger than its pieces of the chunk it is about to read
@@ -79,7 +89,11 @@ __global__ __launch_bounds__(NW * 64) void dfl_k_gemm_r(GemmRArgs a) {
   const int l = tid & 63;
   const int fm = l & 15, fg = l >> 4;  // D layout: row m, columns 4 fg .. 4 fg + 3
   const int u = w / KQ, q = w - u * KQ;
-  const int nch = (a.KS + CK - 1) / CK;
+  // K range of this workgroup: the whole K, or (EPI_F32, grid.y parts: fp32 partial sums for a consumer that adds them —
+  // dfl_norm_frag_batch) k-steps [ks0, ks0 + KSl)
+  const int ks0 = a.ksp ? (int)blockIdx.y * a.ksp : 0;
+  const int KSl = a.ksp ? (a.KS - ks0 < a.ksp ? a.KS - ks0 : a.ksp) : a.KS;
+  const int nch = (KSl + CK - 1) / CK;
   const int nit = (nch + A - 1) / A * A;  // chunk iterations, rounded up to the unroll (clipped weights: zeros)
   const unsigned ring_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)ring;
 
@@ -105,7 +119,7 @@ __global__ __launch_bounds__(NW * 64) void dfl_k_gemm_r(GemmRArgs a) {
   static_assert(NW % MT == 0, "a wave's pieces share a request");
   const int pmt = w % MT;
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<bf16x8 *>(a.xf + pmt * a.frag_stride8), 0, a.KS * 1024, 0x00020000);
+      const_cast<bf16x8 *>(a.xf + pmt * a.frag_stride8 + (size_t)ks0 * 64), 0, KSl * 1024, 0x00020000);
   int pks[SP], poff[SP];
 #pragma unroll
   for (int s = 0; s < SP; ++s) {
@@ -114,64 +128,89 @@ __global__ __launch_bounds__(NW * 64) void dfl_k_gemm_r(GemmRArgs a) {
     pks[s] = i / MT;
     poff[s] = i * 1024;
   }
-  auto stage = [&](int c) {  // chunk c -> slot c % NS
-    const unsigned slot = ring_base + (unsigned)(c % NS) * (NPIECE * 1024);
+  // K is walked in chunks of CK k-steps; workgroup b starts at chunk (b * rot_mul) % nch and wraps: at one moment the
+  // 256 workgroups x <= 16 waves do NOT all ask HBM for the same offset inside their (128 KB-aligned) column tiles.
+  // A pass runs nit >= nch iterations (the unroll's multiple): iterations >= nch are padding (k-steps past K: zeros).
+  const int rot = a.rot_mul ? (int)(((unsigned)blockIdx.x * (unsigned)a.rot_mul) % (unsigned)nch) : 0;
+  auto kchunk = [&](int c) {
+    int k = c + rot;
+    k = k >= nch ? k - nch : k;
+    return c < nch ? k : nch;
+  };
+  int slot_w = 0, slot_r = 0;  // ring slots of the next stage() / the next chunk to compute (cycle 0 .. NS - 1)
+  auto stage = [&](int kc) {   // data chunk kc -> the next ring slot
+    const unsigned slot = ring_base + (unsigned)slot_w * (NPIECE * 1024);
+    slot_w = slot_w + 1 == NS ? 0 : slot_w + 1;
 #pragma unroll
     for (int s = 0; s < SP; ++s)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (r_lds_void *)(uintptr_t)(slot + poff[s]), 16, l * 16, (c * CK + pks[s]) * 1024, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (r_lds_void *)(uintptr_t)(slot + poff[s]), 16, l * 16, (kc * CK + pks[s]) * 1024, 0, 0);
   };
-
-  for (int p = 0; p < a.npass; ++p) {
-    // ---- the wave's unit of this pass
-    const int g = (int)blockIdx.x + (p * a.upp + u) * (int)gridDim.x;
-    const bool have = u < a.upp && g < a.nunits;
-    int tile[TPU];
-    __amdgpu_buffer_rsrc_t wr[TPU];
+  // the wave's unit of pass p: weights base of its TPU tiles and their K extent in bytes (0: no unit — zeros, no traffic)
+  constexpr bool CONT = KQ == 1;  // passes run as ONE pipeline: the last A iterations of a pass request the next pass's first chunks
+  auto unit_of = [&](int p, const bf16x8 *(&base)[TPU], int &bytes, int &g) {
+    g = (int)blockIdx.x + (p * a.upp + u) * (int)gridDim.x;
+    const bool have = p < a.npass && u < a.upp && g < a.nunits;
+#pragma unroll
+    for (int tp = 0; tp < TPU; ++tp) base[tp] = a.wp + ((size_t)(have ? TPU * g + tp : 0) * a.KS + ks0) * 64;
+    bytes = have ? KSl * 1024 : 0;
+  };
+  bf16x8 wreg[A][KPC][TPU];
+  // weights of data chunk kc for this wave: k-steps kc * CK + q * KPC + j of the unit's tiles
+  auto wload1 = [&](bf16x8(&dst)[TPU], const bf16x8 *const(&base)[TPU], int bytes, int kc, int j) {
+    const int soff = (kc * CK + q * KPC + j) * 1024;
 #pragma unroll
     for (int tp = 0; tp < TPU; ++tp) {
-      tile[tp] = TPU * g + tp;
-      wr[tp] = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16x8 *>(a.wp + (size_t)(have ? tile[tp] : 0) * a.KS * 64), 0,
-                                                 have ? a.KS * 1024 : 0, 0x00020000);
+      const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16x8 *>(base[tp]), 0, bytes, 0x00020000);
+      dst[tp] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, l * 16, soff, 2));
     }
-    // weights of chunk c for this wave: k-steps c * CK + q * KPC + j
-    bf16x8 wreg[A][KPC][TPU];
-    auto wload = [&](bf16x8(&dst)[KPC][TPU], int c) {
-      const int soff = (c * CK + q * KPC) * 1024;
+  };
+  auto wload = [&](bf16x8(&dst)[KPC][TPU], const bf16x8 *const(&base)[TPU], int bytes, int kc) {
 #pragma unroll
-      for (int j = 0; j < KPC; ++j)
+    for (int j = 0; j < KPC; ++j) wload1(dst[j], base, bytes, kc, j);
+  };
+
+  const bf16x8 *wcur[TPU], *wnxt[TPU];
+  int bcur, bnxt, gcur, gnxt;
+  unit_of(0, wcur, bcur, gcur);
+  // ---- prologue: the first A chunks, pieces then weights per chunk (the order the immediates below assume)
 #pragma unroll
-        for (int tp = 0; tp < TPU; ++tp)
-          dst[j][tp] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wr[tp], l * 16, soff + j * 1024, 2));
-    };
+  for (int c = 0; c < A; ++c) {
+    stage(kchunk(c));
+    __builtin_amdgcn_sched_barrier(0);
+    wload(wreg[c], wcur, bcur, kchunk(c));
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  for (int p = 0; p < a.npass; ++p) {
+    unit_of(CONT ? p + 1 : a.npass, wnxt, bnxt, gnxt);  // (not CONT: nothing is requested across a pass boundary)
     f32x4 acc[TPU][MT];
 #pragma unroll
     for (int tp = 0; tp < TPU; ++tp)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) acc[tp][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // ---- prologue: the first A chunks, pieces then weights per chunk (the order the immediates below assume)
-    __builtin_amdgcn_s_barrier();  // (a later pass: every wave has left the ring of the pass before)
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int c = 0; c < A; ++c) {
-      stage(c);
-      __builtin_amdgcn_sched_barrier(0);
-      wload(wreg[c], c);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-
     for (int c0 = 0; c0 < nit; c0 += A) {
 #pragma unroll
       for (int ca = 0; ca < A; ++ca) {
         const int c = c0 + ca;
-        // this wave's pieces of chunk c have landed ...
+        // this wave's pieces of the chunk it is about to read have landed ...
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMC) : "memory");
-        // ... and everyone's; every wave has finished reading chunk c - 1, whose slot chunk c + A takes
+        // ... and everyone's; every wave has finished reading the chunk before, whose slot the next request takes
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        stage(c + A);
+        // A chunks ahead: this pass's chunk c + A, or (one pipeline over the passes) the next pass's chunk c + A - nit
+        const int cn = c + A;
+        const bool nx = cn >= nit;
+        const int kcn = nx ? (CONT && p + 1 < a.npass ? kchunk(cn - nit) : nch) : kchunk(cn);
+        stage(kcn);
         __builtin_amdgcn_sched_barrier(0);
-        const unsigned rd = ring_base + (unsigned)(c % NS) * (NPIECE * 1024) + (unsigned)(q * KPC * MT) * 1024 + l * 16;
+        // (uniform selects, not a branch: loads under a branch cost the counted waits)
+        const bf16x8 *wsel[TPU];
+#pragma unroll
+        for (int tp = 0; tp < TPU; ++tp) wsel[tp] = nx ? wnxt[tp] : wcur[tp];
+        const int bsel = nx ? bnxt : bcur;
+        const unsigned rd = ring_base + (unsigned)slot_r * (NPIECE * 1024) + (unsigned)(q * KPC * MT) * 1024 + l * 16;
+        slot_r = slot_r + 1 == NS ? 0 : slot_r + 1;
 #pragma unroll
         for (int j = 0; j < KPC; ++j) {
           bf16x8 b[MT];
@@ -183,23 +222,27 @@ __global__ __launch_bounds__(NW * 64) void dfl_k_gemm_r(GemmRArgs a) {
                 : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3])
                 : "v"(rd + j * MT * 1024)
                 : "memory");
-          } else {
+          } else if constexpr (MT == 2) {
             asm volatile(
                 "ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\t"
                 "s_waitcnt lgkmcnt(0)"
                 : "=&v"(b[0]), "=&v"(b[1])
                 : "v"(rd + j * MT * 1024)
                 : "memory");
+          } else {
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(b[0]) : "v"(rd + j * MT * 1024) : "memory");
           }
 #pragma unroll
           for (int tp = 0; tp < TPU; ++tp)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
               acc[tp][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[ca][j][tp], b[mt], acc[tp][mt], 0, 0, 0);
+          // the registers just consumed take the same k-step of the chunk A ahead at once (past K: clipped, zeros, no
+          // traffic): the wave keeps A chunks of weights in flight all the time, not A - 1 while it computes
+          __builtin_amdgcn_sched_barrier(0);
+          wload1(wreg[ca][j], wsel, bsel, kcn, j);
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        wload(wreg[ca], c + A);  // the registers just consumed take chunk c + A (past K: clipped, zeros, no traffic)
-        __builtin_amdgcn_sched_barrier(0);
       }
     }
 
@@ -230,18 +273,39 @@ __global__ __launch_bounds__(NW * 64) void dfl_k_gemm_r(GemmRArgs a) {
             bestn[mt] = n0 + r;
           }
         }
+      } else if (EPI == EPI_RESID) {
+        bf16_t *hp = a.h_io + mt * a.h_stride + (int64_t)fm * a.ldh + n0;
+        bf16x4 o;
+        if (a.add_resid) {
+          const bf16x4 hv = *reinterpret_cast<const bf16x4 *>(hp);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = f2bf(bf2f(hv[r]) + rbf(s[r]));
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = f2bf(s[r]);
+        }
+        *reinterpret_cast<bf16x4 *>(hp) = o;
+        if (a.tap) *reinterpret_cast<bf16x4 *>(a.tap + mt * a.tap_stride + (int64_t)fm * a.ldtap + n0) = o;
+        if (a.ss_out) {  // (uniform)
+          float q = 0.f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) q += bf2f(o[r]) * bf2f(o[r]);
+          q += __shfl_xor(q, 16, 64);
+          q += __shfl_xor(q, 32, 64);
+          if (fg == 0) a.ss_out[mt * a.ss_stride + t_last * 16 + fm] = q;
+        }
       } else {  // EPI_F32
-        *reinterpret_cast<f32x4 *>(a.out + ((size_t)mt * 16 + fm) * a.ldo + n0) = s;
+        *reinterpret_cast<f32x4 *>(a.out + ((size_t)(blockIdx.y * MT + mt) * 16 + fm) * a.ldo + n0) = s;
       }
     };
 
     if constexpr (KQ == 1) {
-      if (have) {
+      if (bcur) {  // (the wave has a unit in this pass)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) epilogue(tile[TPU - 1], mt, acc[TPU - 1][mt], acc[0][mt]);
+        for (int mt = 0; mt < MT; ++mt) epilogue(TPU * gcur + TPU - 1, mt, acc[TPU - 1][mt], acc[0][mt]);
       }
     } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (dummy pieces past the last chunk still target the ring)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (padding pieces past the last chunk still target the ring)
       __builtin_amdgcn_s_barrier();                     // every wave has left the ring
       asm volatile("" ::: "memory");
       float *red = reinterpret_cast<float *>(ring);     // [NW][TPU][MT][256]
@@ -266,16 +330,38 @@ __global__ __launch_bounds__(NW * 64) void dfl_k_gemm_r(GemmRArgs a) {
       }
       __syncthreads();
     }
+    // ---- the next pass
+#pragma unroll
+    for (int tp = 0; tp < TPU; ++tp) wcur[tp] = wnxt[tp];
+    bcur = bnxt;
+    gcur = gnxt;
+    if (!CONT && p + 1 < a.npass) {  // the ring was reused for the sums: a prologue of its own
+      unit_of(p + 1, wcur, bcur, gcur);
+      slot_r = slot_w;
+#pragma unroll
+      for (int c = 0; c < A; ++c) {
+        stage(kchunk(c));
+        __builtin_amdgcn_sched_barrier(0);
+        wload(wreg[c], wcur, bcur, kchunk(c));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
   }
 
   if (EPI == EPI_ARGMAX) {
-    // every wave leaves its candidates per request: lanes of a row (same fm) differ in fg
+    // the waves' candidates per (request, row) meet in LDS: ONE entry per workgroup goes out (the finish kernel scans
+    // gridDim.x entries per row, not gridDim.x * NW: 30 us -> 5 us at 256 x 16)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (padding pieces past the last chunk still target the ring)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    float *cv = reinterpret_cast<float *>(ring);             // [NW][MT][16]
+    int *ci = reinterpret_cast<int *>(ring) + NW * MT * 16;  // [NW][MT][16]
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       float bv = best[mt];
       int bn = bestn[mt];
 #pragma unroll
-      for (int o = 16; o <= 32; o <<= 1) {
+      for (int o = 16; o <= 32; o <<= 1) {  // lanes of a row (same fm) differ in fg
         const float ov = __shfl_xor(bv, o, 64);
         const int oi = __shfl_xor(bn, o, 64);
         if (ov > bv || (ov == bv && oi < bn)) {
@@ -284,9 +370,25 @@ __global__ __launch_bounds__(NW * 64) void dfl_k_gemm_r(GemmRArgs a) {
         }
       }
       if (fg == 0) {
-        a.best_val[(((size_t)blockIdx.x * NW + w) * MT + mt) * 16 + fm] = bv;
-        a.best_idx[(((size_t)blockIdx.x * NW + w) * MT + mt) * 16 + fm] = bn;
+        cv[(w * MT + mt) * 16 + fm] = bv;
+        ci[(w * MT + mt) * 16 + fm] = bn;
       }
+    }
+    __syncthreads();
+    if (tid < MT * 16) {
+      float bv = -INFINITY;
+      int bn = 0x7fffffff;
+#pragma unroll
+      for (int ww = 0; ww < NW; ++ww) {
+        const float ov = cv[ww * MT * 16 + tid];
+        const int oi = ci[ww * MT * 16 + tid];
+        if (oi != 0x7fffffff && (bn == 0x7fffffff || ov > bv || (ov == bv && oi < bn))) {
+          bv = ov;
+          bn = oi;
+        }
+      }
+      a.best_val[(size_t)blockIdx.x * MT * 16 + tid] = bv;  // [gridDim.x][MT][16]
+      a.best_idx[(size_t)blockIdx.x * MT * 16 + tid] = bn;
     }
   }
 #endif
@@ -294,9 +396,9 @@ __global__ __launch_bounds__(NW * 64) void dfl_k_gemm_r(GemmRArgs a) {
 
 namespace {
 
-template <int MT, int TPU, int KQ, int NW, int A>
+template <int MT, int TPU, int KQ, int NW, int A, int CK = 8>
 constexpr int ring_lds_bytes() {
-  const int ring = (A + 1) * R_CK * MT * 1024, red = KQ > 1 ? NW * TPU * MT * 1024 : 0;
+  const int ring = (A + 1) * CK * MT * 1024, red = KQ > 1 ? NW * TPU * MT * 1024 : 0;
   return ring > red ? ring : red;
 }
 

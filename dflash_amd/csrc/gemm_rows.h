@@ -170,6 +170,7 @@ inline bool fill_src(RowSrc &d, const dfl_rows *s, int K, const char *who) {
   d.eps = s->eps;
   d.valid_word = s->valid_word;
   d.mode = s->mode;
+
   const bool ok = (s->mode == 0 && s->frag) || (s->mode == 1 && s->rows && s->ld >= K && s->ld % 8 == 0) ||
                   (s->mode == 2 && s->rows && s->ss && s->nss >= 1 && s->norm_w && s->ld >= K && s->ld % 8 == 0);
   if (!ok) dfl_set_error("%s: bad row source (mode %d)", who, s->mode);

@@ -340,7 +340,8 @@ class DecodeSession:
         """A cycle that can be replayed: fixed block size, T = 0, no stop ids, no tail clamp even if every token of this
         block and the next is accepted, and the previous cycle left this cycle's draft enqueued (run-ahead)."""
         if not (self.native and self.use_draft and bs == getattr(self, "_graph_bs", None) and self._ahead == bs
-                and self.stop_t is None and not self.stop_always and self.temperature < 1e-5 and self.events is None
+                and self.stop_t is None and not self.stop_always and self.temperature < 1e-5
+                and (self.events is None or not self.record_events)   # (a dict that only receives a run-ahead draft's pairs is fine)
                 and self.start + 2 * bs <= self.max_length and self.start + bs <= self._graph_bound):
             return False
         # The graphs hold RAW device pointers.  A shared draft model / NativeTarget replaces its RoPE table when another
@@ -416,6 +417,9 @@ class DecodeSession:
         # the draft of THIS cycle is in flight already (run-ahead): host bookkeeping of _draft()
         self._ahead = None
         self.dcache.length = start
+        if self.events is not None and self._ahead_ev:   # its event pairs were recorded by the (eager) cycle that enqueued it
+            e = self._ahead_ev
+            self.events["draft"], self.events["lm_head"] = [e[0], e[1]], [e[2], e[3]]
         if self.hook is not None:
             self.hook(self.block[:, :bs], start, self.hook_calls)
         self.hook_calls += 1

@@ -374,6 +374,23 @@ def attn_head_batch(*, xq: torch.Tensor, q_col: int, k_col: int, v_col: int, R: 
         "dfl_attn_head_batch")
 
 
+def attn_head_batch_f32(*, qkv_parts: torch.Tensor, nparts: int, MT: int, ld: int, q_col: int, k_col: int, v_col: int, R: int,
+                        n_q: int, n_kv: int, q_norm_w, k_norm_w, eps, cos_tab, sin_tab, kcache, vcache, layer: int, scale: float,
+                        causal: bool, dyn, kv_len_max: int, ws, max_splits: int, out_frag: torch.Tensor) -> None:
+    """attn_head_batch on the fp32 K-part sums gemm_f32_batch(N = ld) left in qkv_parts ([nparts][MT * 16][ld] floats):
+    the parts meet in the attention launch's row loads (no slab / ticket / combine phase in the GEMM)."""
+    assert qkv_parts.is_cuda and qkv_parts.dtype == F32 and qkv_parts.is_contiguous() and qkv_parts.numel() >= nparts * MT * 16 * ld
+    assert kcache.shape == vcache.shape and kcache.dim() == 5 and kcache.shape[4] == 128 and kcache.is_contiguous()
+    assert out_frag.dim() == 2 and out_frag.is_contiguous()
+    kc, vc = kcache[0, layer], vcache[0, layer]
+    check(lib().dfl_attn_head_batch_f32(
+        qkv_parts.data_ptr(), nparts, MT * 16 * ld, ld, q_col, k_col, v_col, R, 16 * ld, n_q, n_kv,
+        _p(q_norm_w, BF16, "q_norm_w"), _p(k_norm_w, BF16, "k_norm_w"), eps, _p(cos_tab, BF16, "cos"), _p(sin_tab, BF16, "sin"),
+        cos_tab.shape[0], kc.data_ptr(), vc.data_ptr(), kcache.shape[3], kcache.stride(0), scale, int(causal),
+        _p(dyn, I32, "dyn"), kv_len_max, _p(ws), max_splits, _p(out_frag, BF16, "out_frag"), out_frag.stride(0), _stream()),
+        "dfl_attn_head_batch_f32")
+
+
 def topk_rows(logits: torch.Tensor, k: int):
     """logits bf16 [rows, V] (unit inner stride) -> (values fp32 [rows, 8], indices int32 [rows, 8], lse fp32 [rows]);
     columns >= k are unspecified.  Order: value descending, index ascending."""

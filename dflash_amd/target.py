@@ -102,6 +102,7 @@ class NativeTarget:
         self.moe_shared_min = 2       # tiles from which the shared pass is taken (30B-A3B layer: 2 tiles 291 -> 216 us, 4: 576 -> 241)
         self._moe_sh = None
         cfg = hf_model.config
+        self.check_config(cfg)   # (before anything touches the device: a rejected architecture never launches a kernel)
         self.hf = hf_model
         self.model = hf_model.model
         self.lm_head = hf_model.lm_head
@@ -247,9 +248,27 @@ class NativeTarget:
             self.lm_head = _Weight(self.lm_head.weight.detach())
         self.debug_routing = None
         self.gu_events = None   # (layer, start, end): torch.cuda.Event pair recorded around that layer's gate/up GEMM launch
+        # (layer, start, end, n_active_out): the same around that MoE layer's expert gate/up launch; n_active_out (int32 [1],
+        # device) receives the launch's active-expert count right behind the end event (bench.py: bytes = count x expert bytes)
+        self.moe_events = None
         self._rope = None
         self._taps = {}
         torch.cuda.synchronize(dev)
+
+    @staticmethod
+    def check_config(cfg) -> None:
+        """Architectures the kernels do not cover are rejected loudly, before any launch (the reference is shape-agnostic:
+        model/dflash.py:36,42-56 take head_dim, attention_bias and sliding_window from the config; no BASELINE config
+        needs them): head_dim != 128, biased projections, sliding-window attention layers."""
+        n_q = cfg.num_attention_heads
+        hd = getattr(cfg, "head_dim", None) or cfg.hidden_size // n_q
+        if hd != 128:
+            raise NotImplementedError(f"NativeTarget: the gfx950 kernels are built for head_dim == 128 (got {hd}); keep the HF target")
+        if getattr(cfg, "attention_bias", False) or getattr(cfg, "mlp_bias", False):
+            raise NotImplementedError("NativeTarget: biased projections are not supported; keep the HF target")
+        lt = getattr(cfg, "layer_types", None) or ()
+        if any(t == "sliding_attention" for t in lt) and getattr(cfg, "sliding_window", None):
+            raise NotImplementedError("NativeTarget: sliding-window attention layers are not supported; keep the HF target")
 
     # ---- HF-compatible surface (the reference loop can still drive the wrapped model)
     @property
@@ -407,12 +426,18 @@ class NativeTarget:
                           ws["n_active"], dyn=dt, dyn_word=ops.DYN_BS)
             if self.debug_routing is not None and t == 0:    # tests: the routing weights of every MoE layer
                 self.debug_routing.append((i, ws["wt"][0].clone()))
+            mev = self.moe_events if (self.moe_events is not None and self.moe_events[0] == i and t == 0) else None
+            if mev is not None:
+                mev[1].record()
             if H <= 2048 and self.moe_pair_kernel:   # one LDS meeting per (gate, up) tile pair: 64 KB tiles at K = 2048
                 ops.moe_gate_up(lw["gu_e"], ws["xn"][t], E, self.Ie, H, ws["act_e"], ws["elist"], ws["n_active"], dyn=dt,
                                 valid_word=ops.DYN_BS)
             else:
                 ops.gemm_silu_mul_experts(lw["gu_e"], self.src["xn"][t], E, self.Ie, H, ws["act_e"], ws["elist"],
                                           ws["n_active"], dyn=dt)
+            if mev is not None:
+                mev[2].record()
+                mev[3].copy_(ws["n_active"])
             ops.moe_down(lw["down_e"], ws["act_e"], ws["wt"][t], ws["elist"], ws["n_active"], E, H, self.Ie,
                          self.moe_nsplit, ws["moe_part"])
             tap = taps[16 * t:16 * t + 16, sl[0] * H:(sl[0] + 1) * H] if sl else None

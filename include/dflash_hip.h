@@ -282,6 +282,17 @@ int dfl_attn_head_batch(const void *xq, int64_t ldq, int q_col, int k_col, int v
                         const void *sin_tab, int max_pos, void *kcache, void *vcache, int cache_rows,
                         int64_t cache_req_stride, float scale, int causal, const int32_t *dyn, int kv_len_max, void *ws,
                         int max_splits, void *out_frag, int64_t out_req_stride, void *stream);
+/* dfl_attn_head_batch on the fp32 K-PART SUMS of the q/k/v projection (dfl_gemm_f32_batch's output) instead of finished
+ * bf16 rows (model/dflash.py:70-76: a q/k/v value is the Linear's bf16 output = bf16(part 0 + part 1)): request r's rows of
+ * part k at xq_parts + k * part_stride + r * xq_req_stride floats, row stride ldq floats; nparts = dfl_batch_ksplit(hidden)
+ * must be 1 or 2.  The K parts of the projection meet in this launch's row loads, so the GEMM in front of it needs no slab /
+ * ticket / combine phase (qkv at 4 request tiles: 18.3 -> 14.7 us).  Blocks of <= 16 rows. */
+int dfl_attn_head_batch_f32(const float *xq_parts, int nparts, int64_t part_stride, int64_t ldq, int q_col, int k_col,
+                            int v_col, int R, int64_t xq_req_stride, int n_q, int n_kv, const void *q_norm_w,
+                            const void *k_norm_w, float eps, const void *cos_tab, const void *sin_tab, int max_pos,
+                            void *kcache, void *vcache, int cache_rows, int64_t cache_req_stride, float scale, int causal,
+                            const int32_t *dyn, int kv_len_max, void *ws, int max_splits, void *out_frag,
+                            int64_t out_req_stride, void *stream);
 /* The same for blocks of 17..32 rows (q_tiles = 2; benchmark.py's block-size sweep, results.md:11-16, with several requests
  * per GPU): request r is TWO consecutive 16-row tiles of xq and of out_frag (out_tile_stride elements apart), one cache and
  * one length record whose bs counts both tiles.  ws: R * dfl_attn_head_ws_bytes(n_q, max_splits, q_tiles) bytes. */

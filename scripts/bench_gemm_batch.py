@@ -36,6 +36,8 @@ def run(name, kind, N, K):
     d1 = torch.zeros(8, dtype=torch.int32, device=dev)
     ops.set_dyn(d1, 0, 16, 16, 0)
     s1 = ops.rows_plain(x1, ops.DYN_BS)
+    if os.environ.get("SRC") == "frag" and kind in ("resid", "rows"):   # o_proj / down_proj read fragments in the cycle
+        s1 = ops.rows_frag(x1.reshape(-1).contiguous())
     if kind == "f32":
         ks = ops.pick_ksplit(N, K, 1)
         out = torch.empty(ks * 16 * N, device=dev, dtype=torch.float32)
@@ -44,6 +46,9 @@ def run(name, kind, N, K):
         h = torch.zeros(16, N, device=dev, dtype=BF16)
         ss = torch.zeros(N, device=dev)
         us = time_launches(lambda i: ops.gemm_resid(wps[i], s1, N, K, h, add_residual=True, ss_out=ss, dyn=d1), len(wps))
+    elif kind == "rows":     # finished bf16 Linear outputs (the q/k/v rows the attention stage reads)
+        h = torch.zeros(16, N, device=dev, dtype=BF16)
+        us = time_launches(lambda i: ops.gemm_resid(wps[i], s1, N, K, h, add_residual=False, dyn=d1), len(wps))
     elif kind == "silu":
         act = torch.empty(16 * N, device=dev, dtype=BF16)
         us = time_launches(lambda i: ops.gemm_silu_mul(wps[i], s1, N, K, act, d1), len(wps))
@@ -68,6 +73,10 @@ def run(name, kind, N, K):
             ss = torch.zeros(MT, N, device=dev)
             us = time_launches(lambda i: ops.gemm_resid_batch(wps[i], src, R, N, K, h, add_residual=True, ws=ws, dyn=dyn,
                                                               ss_out=ss), len(wps))
+        elif kind == "rows":
+            h = torch.zeros(MT, 16, N, device=dev, dtype=BF16)
+            us = time_launches(lambda i: ops.gemm_resid_batch(wps[i], src, R, N, K, h, add_residual=False, ws=ws, dyn=dyn),
+                               len(wps))
         elif kind == "silu":
             act = torch.empty(MT, 16 * N, device=dev, dtype=BF16)
             us = time_launches(lambda i: ops.gemm_silu_mul_batch(wps[i], src, R, N, K, act, ws, dyn), len(wps))
@@ -81,8 +90,8 @@ def run(name, kind, N, K):
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["all"]
-    shapes = [("qkv", "f32", 6144, 4096), ("o", "resid", 4096, 4096), ("gateup", "silu", 12288, 4096),
-              ("down", "resid", 4096, 12288), ("fc", "resid", 4096, 20480), ("kv_all", "f32", 10240, 4096),
+    shapes = [("qkv", "f32", 6144, 4096), ("qkvr", "rows", 6144, 4096), ("or", "rows", 4096, 4096), ("o", "resid", 4096, 4096), ("gateup", "silu", 12288, 4096),
+              ("down", "resid", 4096, 12288), ("downf", "f32", 4096, 12288), ("of", "f32", 4096, 4096), ("fc", "resid", 4096, 20480), ("kv_all", "f32", 10240, 4096),
               ("lm_head", "argmax", 151936, 4096)]
     for s in shapes:
         if "all" in which or s[0] in which:

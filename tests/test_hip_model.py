@@ -595,6 +595,100 @@ def test_full_size_draft_cycle_matches_oracle():
     H.assert_ids_match_where_safe("8B draft ids", ids[1:], ref_logits, margin_rel=3e-2, min_agree=0.6)
 
 
+def test_full_size_draft_at_the_bench_operating_point():
+    """VERDICT r3 next #5a: the 8B-shaped draft exactly where bench.py runs it — cycle 0 with a 1024-row prompt context
+    (through `_prefill_context_rows`: the prompt's tapped states projected into the draft cache at once) and two steady
+    cycles at S ~ 1024..1040 (tau = 7, then 16) — against `oracle.draft_forward` on the same seeded weights: hidden
+    rows of every cycle, the cached K/V rows of layers 0 and 4 over the whole 1k prefix, and the 151936-way greedy ids
+    on margin-screened rows.  (The bench's `lossless_fraction` cannot see the draft: its hook overwrites the ids.)"""
+    from oracle import dflash_oracle as O
+    from dflash_amd.config import DFlashConfig, QWEN3_8B_DRAFT
+    from dflash_amd import DFlashDraftModel
+    torch.set_num_threads(max(8, torch.get_num_threads()))
+    cfg = DFlashConfig(**QWEN3_8B_DRAFT)
+    w = H.draft_weights(cfg, seed=11, dtype=BF16)
+    m = DFlashDraftModel(cfg, device=dev())
+    m.load_state_dict(w)
+    oc = H.oracle_cfg(cfg, "sdpa")
+    g = torch.Generator().manual_seed(15)
+    ocache = O.ListKVCache()
+    cache = m.new_cache(1024 + 128)
+    start = 1024
+    refs = []
+    for c, (ctx, bs, tau_next) in enumerate(((1024, 16, 7), (7, 16, 16), (16, 16, 4))):
+        th = (torch.randn(1, ctx, cfg.fc_in, generator=g) * 1.5).to(BF16)
+        ne = (torch.randn(1, bs, cfg.hidden_size, generator=g) * 0.05).to(BF16)
+        pos = torch.arange(ocache.get_seq_length(), start + bs)[None]
+        ref = O.draft_forward(w, oc, position_ids=pos, noise_embedding=ne, target_hidden=th, cache=ocache)
+        ocache.crop(start)
+        got = m(target_hidden=th.to(dev()), noise_embedding=ne.to(dev()), position_ids=pos.to(dev()),
+                past_key_values=cache, use_cache=True, is_causal=False)
+        cache.crop(start)
+        H.assert_close(f"8B draft @ S~1k hidden cycle {c} (ctx {ctx})", got, ref)
+        refs.append(ref)
+        start += tau_next
+    n = cache.get_seq_length()
+    assert n == ocache.get_seq_length() == 1024 + 7 + 16
+    for li in (0, 4):
+        H.assert_close(f"8B draft @ S~1k K layer {li}", cache.k[li][:, :n], ocache.k[li][0], max_rel=H.KV_MAX_REL)
+        H.assert_close(f"8B draft @ S~1k V layer {li}", cache.v[li][:, :n], ocache.v[li][0], max_rel=H.KV_MAX_REL)
+    lm = (torch.randn(cfg.vocab_size, cfg.hidden_size, generator=g) * 0.02).to(BF16)
+    ref_logits = torch.nn.functional.linear(refs[-1][0, 1:], lm).float()
+    wp = m.packed_lm_head(lm.to(dev()))
+    ids = torch.zeros(16, dtype=torch.long, device=dev())
+    logits = torch.zeros(16, cfg.vocab_size, dtype=BF16, device=dev())
+    m.draft_tokens(m._src["final"], wp, 16, ids, logits=logits)
+    H.assert_close("8B draft @ S~1k logits (V = 151936)", logits[1:], ref_logits)
+    H.assert_ids_match_where_safe("8B draft @ S~1k ids", ids[1:], ref_logits, margin_rel=3e-2, min_agree=0.6)
+
+
+def test_true_qwen3_4b_shapes_with_tied_embeddings():
+    """VERDICT r3 next #5b: BASELINE configs[0] at its real widths — hidden 2560, FFN 9728, q_dim 4096 != hidden, 5 taps
+    (fc: 12800 -> 2560) — and with TIED embeddings (Qwen3-4B: lm_head.weight is embed_tokens.weight, so the draft's
+    noise rows and its unmask logits come from one tensor, model/dflash.py:237-238): a prompt-context cycle and a steady
+    cycle of the draft forward vs the oracle, block rows embedded from the tied table by the product's own gather, the
+    151936-way logits / ids through the same table."""
+    from oracle import dflash_oracle as O
+    from dflash_amd.config import DFlashConfig, QWEN3_4B_DRAFT
+    from dflash_amd import DFlashDraftModel
+    torch.set_num_threads(max(8, torch.get_num_threads()))
+    cfg = DFlashConfig(**QWEN3_4B_DRAFT)
+    assert (cfg.hidden_size, cfg.intermediate_size, cfg.q_dim, cfg.fc_in) == (2560, 9728, 4096, 12800)
+    w = H.draft_weights(cfg, seed=19, dtype=BF16)
+    m = DFlashDraftModel(cfg, device=dev())
+    m.load_state_dict(w)
+    oc = H.oracle_cfg(cfg, "sdpa")
+    g = torch.Generator().manual_seed(23)
+    tied = (torch.randn(cfg.vocab_size, cfg.hidden_size, generator=g) * 0.05).to(BF16)   # embed_tokens.weight IS lm_head.weight
+    tied_d = tied.to(dev())
+    ocache = O.ListKVCache()
+    cache = m.new_cache(256)
+    start = 70
+    for c, (ctx, bs, tau_next) in enumerate(((70, 16, 9), (9, 16, 16))):
+        th = (torch.randn(1, ctx, cfg.fc_in, generator=g) * 1.5).to(BF16)
+        blk = torch.randint(0, cfg.vocab_size, (bs,), generator=g)
+        blk[1:] = cfg.mask_token_id
+        ne = tied[blk][None]                               # target.model.embed_tokens(block), model/dflash.py:237
+        pos = torch.arange(ocache.get_seq_length(), start + bs)[None]
+        ref = O.draft_forward(w, oc, position_ids=pos, noise_embedding=ne, target_hidden=th, cache=ocache)
+        ocache.crop(start)
+        got = m(target_hidden=th.to(dev()), noise_embedding=tied_d[blk.to(dev())][None], position_ids=pos.to(dev()),
+                past_key_values=cache, use_cache=True, is_causal=False)
+        cache.crop(start)
+        H.assert_close(f"Qwen3-4B widths draft hidden cycle {c}", got, ref)
+        start += tau_next
+    n = cache.get_seq_length()
+    for li in (0, cfg.num_hidden_layers - 1):
+        H.assert_close(f"Qwen3-4B widths draft K layer {li}", cache.k[li][:, :n], ocache.k[li][0], max_rel=H.KV_MAX_REL)
+    ref_logits = torch.nn.functional.linear(ref[0, 1:], tied).float()       # target.lm_head == the embedding table
+    wp = m.packed_lm_head(tied_d)
+    ids = torch.zeros(16, dtype=torch.long, device=dev())
+    logits = torch.zeros(16, cfg.vocab_size, dtype=BF16, device=dev())
+    m.draft_tokens(m._src["final"], wp, 16, ids, logits=logits)
+    H.assert_close("Qwen3-4B widths tied-table logits (V = 151936)", logits[1:], ref_logits)
+    H.assert_ids_match_where_safe("Qwen3-4B widths tied-table ids", ids[1:], ref_logits, margin_rel=3e-2, min_agree=0.6)
+
+
 def test_long_prefix_many_key_splits():
     """Prefix far beyond the bench's 1k (S = 9000: the key-split count saturates at
     max_splits, every split walks many tiles): native verify vs the HF forward."""
