@@ -797,12 +797,16 @@ def main():
 
     # ---- all timing is done: NOW the RCCL communicator (the world size it sees is the one reported) and the reductions
     from dflash_amd import distributed as D
-    grp = None
-    if use_pg and not rehearsal:
-        grp = torch.distributed.new_group(backend="nccl", device_id=dev)   # RCCL
-        world = torch.distributed.get_world_size(grp)
-    elif use_pg:
+    grp, rccl_note = None, None
+    if use_pg:
         world = torch.distributed.get_world_size()
+    if use_pg and not rehearsal:
+        try:
+            grp = torch.distributed.new_group(backend="nccl", device_id=dev)   # RCCL
+            world = torch.distributed.get_world_size(grp)
+            rccl_note = "RCCL group created after the timed regions; timing scalars all-reduced over it"
+        except Exception as e:   # the measurement stands without it: the scalars then travel over the gloo group
+            grp, rccl_note = None, f"RCCL group not created ({type(e).__name__}: {e}); timing scalars reduced over gloo"
 
     def reduce(leg):
         dt_max, tok = D.reduce_timing(leg["dt"], leg["tokens"], device=dev, group=grp)
@@ -858,6 +862,8 @@ def main():
             line["used_block_sizes"] = res["used_block_sizes"]
         if R > 1:
             line["mode"] = res["mode"]
+        if rccl_note:
+            line["collective"] = rccl_note
         if rehearsal:
             line["rehearsal"] = "DFL_BENCH_SHARE_GPU=1: all ranks shared cuda:0 over gloo — control flow only, not a measurement"
         print(json.dumps(line), flush=True)

@@ -11,8 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNEL_SOURCES = ["dflash_amd/csrc/gemm_skinny.hip", "dflash_amd/csrc/gemm_rows.h", "dflash_amd/csrc/dfl_common.h"]
 # --batch: the 4-request leg (bench.py --requests-per-gpu 4): the ragged-batch lm_head / gate-up kernels of gemm_batch.hip
 BATCH_SOURCES = ["dflash_amd/csrc/gemm_batch.hip", "dflash_amd/csrc/gemm_ring.h", "dflash_amd/csrc/gemm_rows.h", "dflash_amd/csrc/dfl_common.h"]
-# (round 4: the ring form, gemm_ring.h: dfl_k_gemm_r<MT, TPU, KQ, NW, A, EPI>)
-BATCH_KERNELS = {"lm_head": ("dfl_k_gemm_r<4,1,1,16,2,2>", 151936 * 4096 * 2), "gate_up": ("dfl_k_gemm_r<4,2,4,12,3,1>", 2 * 12288 * 4096 * 2)}
+# (round 4: the ring form, gemm_ring.h: dfl_k_gemm_r<MT, TPU, KQ, NW, A, EPI, CK>)
+BATCH_KERNELS = {"lm_head": ("dfl_k_gemm_r<4,1,1,16,2,2,8>", 151936 * 4096 * 2), "gate_up": ("dfl_k_gemm_r<4,2,4,12,2,1,8>", 2 * 12288 * 4096 * 2)}
 # (round 3 names: k_gemm<MT, CHUNKED, EPI, NORM>; the normalised-source instantiations are the ones the cycle runs)
 KERNELS = {"gate_up": ("k_gemm<1,false,1,true>", 2 * 12288 * 4096 * 2), "lm_head": ("k_gemm<1,false,2,true>", 151936 * 4096 * 2)}
 
