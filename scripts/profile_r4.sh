@@ -38,6 +38,11 @@ case "${1:-all}" in
   pmc1) run_pmc "" --target-layers 8 --no-batch4 ;;
   pmc4) run_pmc "_b4" --target-layers 8 --requests-per-gpu 4 ;;
   pmcm) run_pmc "_moe" --target-layers 6 --workload qwen3-30b-a3b ;;
+  attn)    # the attention stage's split knobs in the N = 1 cycle: one old-key split per head = 64 workgroups
+    cd "$R"
+    for rep in 1 2; do for w in 224 64 96; do
+      DFL_ATTN_HEAD_WGS=$w python3 bench.py --no-cpu-baseline --no-batch4 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.readline()); print('N=1 attn_head_wgs=$w', round(d['ms_per_step'],4), d['lossless_fraction'])"
+    done; done ;;
   lines)   # the bench lines kept under profiles/ (un-profiled, replay where the workload allows it)
     cd "$R"
     python3 bench.py > "$O/r4_bench_n1.json" 2> "$O/r4_bench_n1.err"; tail -c 300 "$O/r4_bench_n1.err"
