@@ -73,6 +73,7 @@ SIGNATURES = {
     "dfl_topk_rows": (_i, [_p, _i64, _i, _i, _i, _p, _p, _p, _p]),
     "dfl_candidate_select": (_i, [_p, _i64, _p, _i64, _p, _i, _i, _p, _i64, _p, _p, _i, _p, _p]),
     "dfl_moe_route": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p]),
+    "dfl_moe_router": (_i, [_p, _i64, _p, _f, _p, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _i, _p, _p]),
     "dfl_gemm_silu_mul_experts": (_i, [_p, _i64, _r, _i, _i, _i, _p, _i64, _p, _p, _p, _p]),
     "dfl_moe_gate_up": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _p, _i, _p]),
     "dfl_moe_down": (_i, [_p, _i64, _p, _i64, _p, _p, _p, _i, _i, _i, _i, _p, _p]),

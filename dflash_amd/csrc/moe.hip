@@ -3,6 +3,7 @@
 // Qwen3MoeExperts.forward).  For the <= 16 block rows of a verify:
 //   k_moe_route   router logits [16][E] (bf16, the gate Linear's output) -> fp32 softmax -> top-k -> normalised bf16
 //                 weights as a dense [16][E] matrix (0 = not routed), the ascending list of experts some row uses
+//   k_moe_router  the block's RMSNorm + the gate Linear + that routing in one launch (round 4)
 //   (dfl_gemm_silu_mul_experts, gemm_skinny.hip: act_e = silu(x Wg_e^T) * (x Wu_e^T) for every active expert)
 //   k_moe_down    out[m][n] = sum over active experts e of w[m][e] * (act_e[m] . Wd_e[n]) as fp32 K-part sums: one MFMA
 //                 tile of 16 output columns per workgroup, the active experts dealt to its 16 waves, each wave scaling
@@ -12,48 +13,321 @@
 // dense MLP's Linear output is rounded — fewer roundings than the reference, inside the stated bf16 tolerance.
 #include "gemm_rows.h"
 #include "moe_route.h"
+#include <limits.h>
 
 namespace {
 
-// one wavefront per row (16 rows), E <= 256
-__global__ __launch_bounds__(1024) void k_moe_route(const bf16_t *logits, int ld, int E, int top_k, int norm_topk,
-                                                    bf16_t *wt, int32_t *active, int32_t *list, int32_t *n_active,
-                                                    const int32_t *dyn, int dyn_word) {
-  const int tid = threadIdx.x, m = tid >> 6, l = tid & 63;
-  const int nv = dyn ? dyn[dyn_word] : 16;
-  for (int e = tid; e < E; e += 1024) active[e] = 0;
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int e = l + 64 * j;
-    if (e < E) wt[(int64_t)m * E + e] = (bf16_t)0.f;
+#ifdef DFL_MOE_STAMPS  // diagnostic build only (scripts/dbg_moe_router_stamps.py): 100 MHz wall stamps of every workgroup
+__device__ unsigned long long g_rstamps[16][12];
+#define RSTAMP(i)                                                                            \
+  do {                                                                                       \
+    if (threadIdx.x == 0) g_rstamps[blockIdx.x][i] = __builtin_amdgcn_s_memrealtime();       \
+  } while (0)
+#else
+#define RSTAMP(i)
+#endif
+
+// workgroup barrier for LDS traffic only (__syncthreads() also waits for every global store in flight: ~1 us each
+// time behind the routing kernels' output stores)
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// max / min over the 16 lanes of a DPP row, result in each of them
+__device__ __forceinline__ float row_max16(float v) {
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)));
+  return v;
+}
+__device__ __forceinline__ long long row_max16_i64(long long v) {
+#define DFL_STEP64(ctrl)                                                                                         \
+  {                                                                                                              \
+    const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)v, ctrl, 0xF, 0xF, true);              \
+    const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)((unsigned long long)v >> 32), ctrl, 0xF, 0xF, true); \
+    const long long o = (long long)(((unsigned long long)hi << 32) | lo);                                         \
+    v = o > v ? o : v;                                                                                            \
   }
-  float sel_v[8], tot;
-  int sel_i[8];
-  route_row(logits + (int64_t)m * ld, E, top_k, l, sel_v, sel_i, tot);
-  if (m < nv && l == 0) {
+  DFL_STEP64(0xB1) DFL_STEP64(0x4E) DFL_STEP64(0x141) DFL_STEP64(0x140)
+#undef DFL_STEP64
+  return v;
+}
+__device__ __forceinline__ int row_min16(int v) {
+  v = min(v, __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true));
+  v = min(v, __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true));
+  v = min(v, __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true));
+  v = min(v, __builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, true));
+  return v;
+}
+
+// Routing of the 16 rows by a workgroup of >= 4 waves (E <= 16 EJ): a QUARTER wave per row — the 16 lanes of a DPP row
+// own experts q, q + 16, ... of row 4 w + (l >> 4), so every reduction of the softmax and of the k selection rounds is
+// four DPP steps inside the row, for four rows per instruction.  (First form: one wavefront per row, 16 waves = four per
+// SIMD taking turns at ~700 instructions each: 6.8 us of the launch by its stamps, scripts/dbg_moe_router_stamps.py.)
+// Arithmetic of route_row (moe_route.h): fp32 softmax of the bf16 logits, k rounds of (largest probability, lowest
+// expert), optional renormalisation by the sum taken in selection order; a NaN row gives experts 0 .. k-1 NaN weights.
+// lg: the 16 rows' logits, row stride ld (LDS or global).  The active flags meet in LDS (s_act[256]); nothing waits
+// for a global store.
+template <int EJ>
+__device__ __forceinline__ void route_rows(const bf16_t *lg, int ld, int E, int top_k, int norm_topk, int nv, bf16_t *wt,
+                                           int32_t *active, int32_t *list, int32_t *n_active, int *s_act) {
+  __shared__ float s_sv[16 * 8];
+  __shared__ int s_si[16 * 8];
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+  if (tid < 256) s_act[tid] = 0;
+  lds_barrier();
+  RSTAMP(8);
+  if (w < 4) {
+    const int row = 4 * w + (l >> 4), q = l & 15;
+    // BRANCH-FREE throughout: one wave alone on its SIMD pays every exec-mask branch in full (the first form's
+    // `if (e < E && p > best)` per expert cost 16 branches per round: 0.37 us per round by the stamps)
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(wt, 0, 16 * E * (int)sizeof(bf16_t), 0x00020000);
+    float p[EJ];
+    float mx = -INFINITY;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      if (r < top_k) {
-        const float w = norm_topk ? sel_v[r] / tot : sel_v[r];
-        wt[(int64_t)m * E + sel_i[r]] = f2bf(w);
-        active[sel_i[r]] = 1;
-      }
+    for (int j = 0; j < EJ; ++j) {
+      const int e = q + 16 * j;
+      const int ec = e < E ? e : 0;  // (clamped: no branch around the load)
+      const float v = bf2f(lg[(int64_t)row * ld + ec]);
+      p[j] = e < E ? v : -INFINITY;
+      // zero the row's dense weights (past E: an offset beyond the descriptor, dropped)
+      __builtin_amdgcn_raw_buffer_store_b16((unsigned short)0, wr, e < E ? (row * E + e) * (int)sizeof(bf16_t) : 0x40000000, 0, 0);
+      mx = fmaxf(mx, p[j]);
+    }
+    mx = row_max16(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < EJ; ++j) {
+      p[j] = (q + 16 * j) < E ? __expf(p[j] - mx) : 0.f;
+      sum += p[j];
+    }
+    sum = row_sum16(sum);
+    // One sortable 64-bit key per expert: the probability's bits (>= 0: they order as integers; a NaN canonical and above
+    // everything) over INT_MAX - expert, so that a plain integer max IS "largest probability, lowest expert" — a round
+    // is 7 maxima in the lane, 4 DPP steps in the row and 8 compares to retire the winner (~70 instructions; the first
+    // forms — (value, index) pairs through compare / select trees — were ~250 per round at 4 cycles each for a wave
+    // alone on its SIMD: 0.45 us per round by the stamps).  A NaN row selects experts 0 .. k-1 with NaN weights, as
+    // route_row does.
+    long long key[EJ];
+#pragma unroll
+    for (int j = 0; j < EJ; ++j) {
+      const int e = q + 16 * j;
+      const float pj = p[j] / sum;  // softmax(dtype = float)
+      const int bits = pj == pj ? __float_as_int(pj) : 0x7fc00000;
+      key[j] = e < E ? (long long)(((unsigned long long)(unsigned)bits << 32) | (unsigned)(0x7fffffff - e)) : LLONG_MIN;
+    }
+    RSTAMP(9);
+    float tot = 0.f;
+#pragma unroll 1  // (a ROLLED loop: the launch runs this code once, from a cold instruction cache)
+    for (int r = 0; r < top_k; ++r) {
+      long long best = key[0];
+#pragma unroll
+      for (int j = 1; j < EJ; ++j) best = key[j] > best ? key[j] : best;
+      best = row_max16_i64(best);
+      const float bv = __int_as_float((int)(best >> 32));
+      tot += bv;  // (selection order, as route_row sums it)
+      s_sv[row * 8 + r] = bv;  // (all 16 lanes of the row: the same value to the same word)
+      s_si[row * 8 + r] = 0x7fffffff - (int)(unsigned)best;
+#pragma unroll
+      for (int j = 0; j < EJ; ++j) key[j] = key[j] == best ? LLONG_MIN : key[j];  // taken
+    }
+    RSTAMP(10);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the row's own lane 0 wrote them: same wave, in order)
+    if (row < nv && q < top_k) {  // lane q writes selection q (behind this wave's own zero stores of the row: in order)
+      const float v = s_sv[row * 8 + q];
+      const int e = s_si[row * 8 + q];
+      wt[(int64_t)row * E + e] = f2bf(norm_topk ? v / tot : v);
+      s_act[e] = 1;
     }
   }
-  __syncthreads();
-  // ascending list of the active experts (wave 0)
-  if (m == 0) {
+  lds_barrier();
+  RSTAMP(11);
+  for (int e = tid; e < E; e += (int)blockDim.x) active[e] = s_act[e];
+  if (w == 0) {  // ascending list of the active experts
     int base = 0;
     for (int e0 = 0; e0 < E; e0 += 64) {
       const int e = e0 + l;
-      const bool a = e < E && active[e] != 0;
-      const unsigned long long b = __ballot(a);
-      if (a) list[base + __popcll(b & ((1ull << l) - 1ull))] = e;
-      base += __popcll(b);
+      const bool on = e < E && s_act[e] != 0;
+      const unsigned long long bb = __ballot(on);
+      if (on) list[base + __popcll(bb & ((1ull << l) - 1ull))] = e;
+      base += __popcll(bb);
     }
     if (l == 0) *n_active = base;
   }
+}
+
+__global__ __launch_bounds__(256) void k_moe_route(const bf16_t *logits, int ld, int E, int top_k, int norm_topk,
+                                                   bf16_t *wt, int32_t *active, int32_t *list, int32_t *n_active,
+                                                   const int32_t *dyn, int dyn_word) {
+  __shared__ int s_act[256];
+  const int nv = dyn ? dyn[dyn_word] : 16;
+  if (E <= 128)
+    route_rows<8>(logits, ld, E, top_k, norm_topk, nv, wt, active, list, n_active, s_act);
+  else
+    route_rows<16>(logits, ld, E, top_k, norm_topk, nv, wt, active, list, n_active, s_act);
+}
+
+// ---- RMSNorm + router GEMM + routing of the <= 16 rows in ONE launch (round 4).  The three launches it replaces
+// (k_norm_pack 4.5 us, the router's 8-workgroup k_gemm 4.8 us, k_moe_route 8.7 us — 4.7 us with this round's
+// routing code — plus two boundaries) are pure latency: 64 KB of rows, 512 KB of router weights, 4 KB of logits —
+// 15 % of a 48-layer verify (BASELINE configs[4]).  Stamps of this launch at the 30B-A3B shape
+// (profiles/r4_moe_router_stamps.txt, us from its start): rows + weights landed 3.7 · normalised, multiplied, met in
+// LDS 5.9 · logits stored, ticket back 7.3 · (last workgroup) logits in LDS 8.9, softmax 10.2, k rounds 12.4,
+// list 13.4; 12.8 us by the kernel trace against 13.9 + two boundaries.
+// Here workgroup b (one per 16-expert column tile of the gate Linear) normalises the rows itself while it builds its
+// MFMA B operands (each wave its own k-steps, straight from the residual rows in fragment order; the row's sum of
+// squares meets in LDS), writes its share of the normalised fragments for the expert GEMMs, multiplies with its tile
+// of the router weights, rounds the 16 x 16 logits to bf16 (the gate Linear's output) and hands them over: sc1
+// 16-byte stores by wave 0, drained, the workgroup's barrier, ONE returning agent-scope add by one lane; the
+// workgroup whose add came last loads all logits with sc1 4-byte loads behind its barrier
+// (MI355X_MICROARCH.md, "Valid forms", table row 1: the last arriver is told by the returned value; no spinning,
+// nothing to deadlock) and routes as k_moe_route does (route_rows above).
+struct MoeRouterArgs {
+  const bf16_t *h;  // [16][ldh] residual rows to normalise; null: xn holds the normalised fragments already
+  int64_t ldh;
+  const bf16_t *nw;
+  float eps;
+  bf16x8 *xn;        // frag16 [KS][64]: written (h != null) or read
+  const bf16x8 *wr;  // packed router weights [Ep/16][KS][64]
+  int KS, E, top_k, norm_topk;
+  bf16_t *rlog;  // [16][ld] bf16 logits (the hand-off buffer; a test reads it)
+  int ld;
+  bf16_t *wt;
+  int32_t *active, *list, *n_active;
+  const int32_t *dyn;
+  int dyn_word;
+  int *ticket;  // zero between launches
+};
+
+template <int FR, bool NORM>
+__global__ __launch_bounds__(1024) void k_moe_router(MoeRouterArgs a) {
+  __shared__ float red[16][256];
+  __shared__ float ssw[16][16];
+  __shared__ __attribute__((aligned(16))) bf16_t tile[16][16];
+  __shared__ int s_last;
+  __shared__ int s_act[256];
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
+  const int b = blockIdx.x, nwg = gridDim.x;
+  const int m = l & 15, kq = l >> 4;
+  const int ks0 = w * FR;
+  RSTAMP(0);
+  int nf = a.KS - ks0;
+  nf = __builtin_amdgcn_readfirstlane(nf < 0 ? 0 : (nf > FR ? FR : nf));
+  bf16x8 wv[FR], x[FR];
+  // the router weights first (K <= 2048); with 8 k-steps per wave they would not fit beside the rows being normalised
+  // (128 VGPRs at 1024 threads) and are asked for behind the normalisation instead
+  if constexpr (!(NORM && FR > 4)) load_ksteps<FR>(wv, a.wr + ((size_t)b * a.KS + ks0) * 64, nf, l);
+  const int nv = a.dyn ? a.dyn[a.dyn_word] : 16;
+  if (NORM) {
+    bf16x8 g[FR];
+#pragma unroll
+    for (int f = 0; f < FR; ++f) {
+      const int ks = f < nf ? ks0 + f : 0;  // (clamped: no branch around a load; all 16 rows are readable memory)
+      x[f] = *reinterpret_cast<const bf16x8 *>(a.h + (int64_t)m * a.ldh + ks * 32 + kq * 8);
+      if constexpr (FR <= 4) g[f] = *reinterpret_cast<const bf16x8 *>(a.nw + ks * 32 + kq * 8);
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int f = 0; f < FR; ++f)
+      if (f < nf)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss += bf2f(x[f][j]) * bf2f(x[f][j]);
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
+    if (kq == 0) ssw[w][m] = ss;
+    __syncthreads();
+  RSTAMP(1);
+    float tot = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < 16; ++ww) tot += ssw[ww][m];
+    const float rstd = rsqrtf(tot / (float)(a.KS * 32) + a.eps);  // Qwen3MoeRMSNorm: fp32 mean of squares
+#pragma unroll
+    for (int f = 0; f < FR; ++f) {
+      if constexpr (FR > 4)  // (K > 2048: the norm weights are asked for only now — 8 + 8 + 8 fragments do not fit 128 VGPRs)
+        g[f] = *reinterpret_cast<const bf16x8 *>(a.nw + (f < nf ? ks0 + f : 0) * 32 + kq * 8);
+      const bool live = f < nf && m < nv;  // absent rows: zero fragments
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[f][j] = live ? f2bf(bf2f(g[f][j]) * rbf(bf2f(x[f][j]) * rstd)) : (bf16_t)0.f;
+    }
+  } else {
+    load_ksteps<FR, 0>(x, a.xn + (size_t)ks0 * 64, nf, l);
+  }
+  if constexpr (NORM && FR > 4) {  // (K > 2048: the fragments leave at once; kept through the routing they spill)
+    load_ksteps<FR>(wv, a.wr + ((size_t)b * a.KS + ks0) * 64, nf, l);
+#pragma unroll
+    for (int f = 0; f < FR; ++f)
+      if (f < nf && (ks0 + f) % nwg == b) a.xn[(size_t)(ks0 + f) * 64 + l] = x[f];
+  }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int f = 0; f < FR; ++f) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[f], x[f], acc, 0, 0, 0);
+  *reinterpret_cast<f32x4 *>(&red[w][l * 4]) = acc;
+  __syncthreads();
+  RSTAMP(2);
+  if (tid < 256) {  // D layout: lane L, register r = column 4 (L >> 4) + r of row L & 15
+    const int mm = tid >> 4, nl = tid & 15;
+    const int idx = 4 * (mm + 16 * (nl >> 2)) + (nl & 3);
+    float s = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < 16; ++ww) s += red[ww][idx];
+    tile[mm][nl] = f2bf(s);
+  }
+  __syncthreads();
+  RSTAMP(3);
+  if (tid < 32) {  // (wave 0) row tid >> 1, experts 16 b + 8 (tid & 1) .. + 7: one 16-byte write-through store
+    const __amdgpu_buffer_rsrc_t rr =
+        __builtin_amdgcn_make_buffer_rsrc(a.rlog, 0, 16 * a.ld * (int)sizeof(bf16_t), 0x00020000);
+    const u32x4 v = *reinterpret_cast<const u32x4 *>(&tile[tid >> 1][8 * (tid & 1)]);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rr, ((tid >> 1) * a.ld + 16 * b + 8 * (tid & 1)) * (int)sizeof(bf16_t), 0, 16);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (only wave 0 has stores in flight: the logits)
+  RSTAMP(4);
+  lds_barrier();
+  if (tid == 0) {
+    const int t = __hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = t == nwg - 1;
+    if (last) __hip_atomic_store(a.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
+    s_last = last;
+  }
+  RSTAMP(5);
+  // this workgroup's share of the normalised fragments (the expert GEMMs' source) leaves LAST: in front of the hand-off
+  // or of the logits' loads its stores would lengthen their waits (a wave's vmcnt counts them all)
+  auto store_xn = [&]() {
+    if (NORM && FR <= 4) {
+#pragma unroll
+      for (int f = 0; f < FR; ++f)
+        if (f < nf && (ks0 + f) % nwg == b) a.xn[(size_t)(ks0 + f) * 64 + l] = x[f];
+    }
+  };
+  lds_barrier();
+  if (!s_last) {
+    store_xn();
+    return;
+  }
+  // ---- the last workgroup to arrive routes: every logit through an sc1 load into LDS, then k_moe_route's body
+  bf16_t *lg = reinterpret_cast<bf16_t *>(&red[0][0]);  // [16][E] (E <= 256: 8 KB of the 16 KB)
+  {
+    const __amdgpu_buffer_rsrc_t rr =
+        __builtin_amdgcn_make_buffer_rsrc(a.rlog, 0, 16 * a.ld * (int)sizeof(bf16_t), 0x00020000);
+    const int half = a.E >> 1;  // pairs of experts per row (E even)
+    for (int i = tid; i < 16 * half; i += 1024) {
+      const int mm = i / half, p = i - mm * half;
+      const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rr, (mm * a.ld + 2 * p) * (int)sizeof(bf16_t), 0, 16);
+      *reinterpret_cast<unsigned *>(&lg[mm * a.E + 2 * p]) = v;
+    }
+  }
+  lds_barrier();
+  RSTAMP(6);
+  if (a.E <= 128)
+    route_rows<8>(lg, a.E, a.E, a.top_k, a.norm_topk, nv, a.wt, a.active, a.list, a.n_active, s_act);
+  else
+    route_rows<16>(lg, a.E, a.E, a.top_k, a.norm_topk, nv, a.wt, a.active, a.list, a.n_active, s_act);
+  RSTAMP(7);
+  store_xn();
 }
 
 struct MoeDownArgs {
@@ -244,11 +518,64 @@ extern "C" int dfl_moe_route(const void *logits, int ld, int E, int top_k, int n
   DFL_REQUIRE(logits && wt && active && list && n_active, "dfl_moe_route: null pointer");
   DFL_REQUIRE(E >= 1 && E <= 256 && ld >= E && top_k >= 1 && top_k <= 8 && top_k <= E, "dfl_moe_route: E=%d top_k=%d outside range",
               E, top_k);
-  hipLaunchKernelGGL(k_moe_route, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const bf16_t *)logits, ld, E, top_k,
+  hipLaunchKernelGGL(k_moe_route, dim3(1), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)logits, ld, E, top_k,
                      norm_topk ? 1 : 0, (bf16_t *)wt, active, list, n_active, dyn, dyn_word);
   DFL_CHECK_LAUNCH("dfl_moe_route");
   return DFL_OK;
 }
+
+extern "C" int dfl_moe_router(const void *h, int64_t ldh, const void *norm_w, float eps, void *xn_frag, const void *wp_router,
+                              int K, int E, int top_k, int norm_topk, void *rlog, int ld, void *wt, int32_t *active,
+                              int32_t *list, int32_t *n_active, const int32_t *dyn, int dyn_word, int32_t *ticket,
+                              void *stream) {
+  DFL_REQUIRE(xn_frag && wp_router && rlog && wt && active && list && n_active && ticket, "dfl_moe_router: null pointer");
+  DFL_REQUIRE(!h || (norm_w && ldh >= K && ldh % 8 == 0), "dfl_moe_router: rows to normalise need norm_w and ldh >= K, ldh %% 8 == 0");
+  DFL_REQUIRE(K >= 32 && K % 32 == 0 && K <= 4096, "dfl_moe_router: K=%d outside 32..4096 (multiples of 32)", K);
+  DFL_REQUIRE(E >= 2 && E <= 256 && E % 2 == 0 && top_k >= 1 && top_k <= 8 && top_k <= E, "dfl_moe_router: E=%d top_k=%d outside range", E,
+              top_k);
+  const int Ep = (E + 15) / 16 * 16;
+  DFL_REQUIRE(ld >= Ep && ld % 8 == 0, "dfl_moe_router: ld=%d shorter than the padded expert count %d or not a multiple of 8", ld, Ep);
+  MoeRouterArgs a{};
+  a.h = (const bf16_t *)h;
+  a.ldh = ldh;
+  a.nw = (const bf16_t *)norm_w;
+  a.eps = eps;
+  a.xn = (bf16x8 *)xn_frag;
+  a.wr = (const bf16x8 *)wp_router;
+  a.KS = K / 32;
+  a.E = E;
+  a.top_k = top_k;
+  a.norm_topk = norm_topk ? 1 : 0;
+  a.rlog = (bf16_t *)rlog;
+  a.ld = ld;
+  a.wt = (bf16_t *)wt;
+  a.active = active;
+  a.list = list;
+  a.n_active = n_active;
+  a.dyn = dyn;
+  a.dyn_word = dyn_word;
+  a.ticket = ticket;
+  const dim3 grid(Ep / 16), block(1024);
+  if (K <= 2048) {
+    if (h)
+      hipLaunchKernelGGL((k_moe_router<4, true>), grid, block, 0, (hipStream_t)stream, a);
+    else
+      hipLaunchKernelGGL((k_moe_router<4, false>), grid, block, 0, (hipStream_t)stream, a);
+  } else {
+    if (h)
+      hipLaunchKernelGGL((k_moe_router<8, true>), grid, block, 0, (hipStream_t)stream, a);
+    else
+      hipLaunchKernelGGL((k_moe_router<8, false>), grid, block, 0, (hipStream_t)stream, a);
+  }
+  DFL_CHECK_LAUNCH("dfl_moe_router");
+  return DFL_OK;
+}
+
+#ifdef DFL_MOE_STAMPS
+extern "C" int dfl_debug_read_router_stamps(unsigned long long *host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_rstamps), sizeof(unsigned long long) * 16 * 12);
+}
+#endif
 
 extern "C" int dfl_moe_down(const void *wp_down, int64_t wp_expert_stride, const void *act_frag, int64_t act_expert_stride,
                             const void *wt, const int32_t *list, const int32_t *n_active, int E, int N, int I, int nsplit,

@@ -45,15 +45,11 @@ __device__ __forceinline__ void route_row(const bf16_t *logits_row, int E, int t
         bi = e;
       }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(bv, o, 64);
-      const int oi = __shfl_xor(bi, o, 64);
-      if (route_better(ov, oi, bv, bi)) {
-        bv = ov;
-        bi = oi;
-      }
-    }
+    // the wave's best: the largest probability, and among the lanes that hold it the lowest expert (two DPP
+    // reductions; a NaN row leaves bv = -1 / bi = INT_MAX in every lane, handled below)
+    const float mv = wave_max(bv);
+    bi = wave_min_i32(bv == mv ? bi : 0x7fffffff);
+    bv = mv;
     if (bi == 0x7fffffff) {  // a NaN row (one NaN logit makes every probability NaN): no comparison succeeded.  The index
       bi = r;                // feeds LDS / global counters downstream (k_pmoe_plan, k_moe_route), so it must stay < E: round
       bv = p[0] + p[1];      // r takes expert r (distinct per round, top_k <= E) with a NaN weight — the NaN propagates

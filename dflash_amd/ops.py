@@ -428,6 +428,23 @@ def moe_route(logits: torch.Tensor, E: int, top_k: int, norm_topk: bool, wt: tor
                               _stream()), "dfl_moe_route")
 
 
+def moe_router(*, h: Optional[torch.Tensor], norm_w: Optional[torch.Tensor], eps: float, xn: torch.Tensor, wp_router: torch.Tensor,
+               K: int, E: int, top_k: int, norm_topk: bool, rlog: torch.Tensor, wt: torch.Tensor, active: torch.Tensor,
+               lst: torch.Tensor, n_active: torch.Tensor, ticket: torch.Tensor, dyn=None, dyn_word: int = 0) -> None:
+    """RMSNorm (h [16, >= K] rows -> xn frag16; h None: xn is the input) + gate Linear + moe_route in one launch.
+    rlog bf16 [16, ld]; ticket int32 [1], zero."""
+    assert rlog.dtype == BF16 and rlog.dim() == 2 and rlog.stride(1) == 1 and rlog.shape[0] >= 16
+    assert wt.dtype == BF16 and wt.is_contiguous() and wt.numel() >= 16 * E and xn.numel() >= 16 * K
+    hp, ldh = None, 0
+    if h is not None:
+        assert h.is_cuda and h.dtype == BF16 and h.dim() == 2 and h.stride(1) == 1 and h.shape[0] >= 16 and h.shape[1] >= K
+        hp, ldh = h.data_ptr(), h.stride(0)
+    check(lib().dfl_moe_router(hp, ldh, _p(norm_w, BF16, "norm_w"), eps, _p(xn, BF16, "xn"), _p(wp_router, BF16, "wp_router"), K, E,
+                               top_k, int(norm_topk), rlog.data_ptr(), rlog.stride(0), _p(wt), _p(active, I32, "active"),
+                               _p(lst, I32, "list"), _p(n_active, I32, "n_active"), _p(dyn, I32, "dyn"), dyn_word,
+                               _p(ticket, I32, "ticket"), _stream()), "dfl_moe_router")
+
+
 def gemm_silu_mul_experts(wp_gu: torch.Tensor, x, E: int, I: int, K: int, act: torch.Tensor, lst: torch.Tensor,
                           n_active: torch.Tensor, dyn=None) -> None:
     """wp_gu bf16 [E, 2*I*K] packed per expert; act bf16 [E, 16*I] (frag16 per expert); lst / n_active: the active

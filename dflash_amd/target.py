@@ -18,6 +18,7 @@ loops of this package detect it and take the fast path instead:
 """
 from __future__ import annotations
 
+import os
 from types import SimpleNamespace
 from typing import Optional, Sequence
 
@@ -216,7 +217,10 @@ class NativeTarget:
                            act_e=z(self.E, 16 * self.Ie), moe_part=z(self.moe_nsplit, 16, self.H, dt=torch.float32),
                            active=torch.zeros(self.E, dtype=torch.int32, device=dev),
                            elist=torch.zeros(self.E, dtype=torch.int32, device=dev),
-                           n_active=torch.zeros(1, dtype=torch.int32, device=dev))
+                           n_active=torch.zeros(1, dtype=torch.int32, device=dev),
+                           rticket=torch.zeros(1, dtype=torch.int32, device=dev))
+            # norm + gate Linear + routing as ONE launch (dfl_moe_router; DFL_MOE_ROUTER=split: the three launches)
+            self.moe_router_fused = (os.environ.get("DFL_MOE_ROUTER", "fused") != "split" and self.H <= 4096 and self.E % 2 == 0)
         ws, nt = self.ws, self.H // 16
         hs = [ws["h"][16 * t:16 * t + 16] for t in range(NT)]
         # row sources, one per tile: the consuming GEMM applies the RMSNorm itself (no norm launches)
@@ -419,11 +423,18 @@ class NativeTarget:
         ws, H, E = self.ws, self.H, self.E
         nxt = self.layers[i + 1]["ln1"] if i + 1 < self.L else self.norm
         for t, dt in tiles:
-            ops.norm_pack(norm_w=lw["ln2"], frag=ws["xn"][t], H=H, eps=self.eps, resid_in=hrow[t], dyn=dt,
-                          dyn_word=ops.DYN_BS)
-            ops.gemm_resid(lw["router"], self.src["xn"][t], ws["rlog"].shape[2], H, ws["rlog"][t], add_residual=False, dyn=dt)
-            ops.moe_route(ws["rlog"][t], E, self.top_k, self.norm_topk, ws["wt"][t], ws["active"], ws["elist"],
-                          ws["n_active"], dyn=dt, dyn_word=ops.DYN_BS)
+            if self.moe_router_fused:
+                ops.moe_router(h=hrow[t], norm_w=lw["ln2"], eps=self.eps, xn=ws["xn"][t], wp_router=lw["router"], K=H, E=E,
+                               top_k=self.top_k, norm_topk=self.norm_topk, rlog=ws["rlog"][t], wt=ws["wt"][t],
+                               active=ws["active"], lst=ws["elist"], n_active=ws["n_active"], ticket=ws["rticket"], dyn=dt,
+                               dyn_word=ops.DYN_BS)
+            else:
+                ops.norm_pack(norm_w=lw["ln2"], frag=ws["xn"][t], H=H, eps=self.eps, resid_in=hrow[t], dyn=dt,
+                              dyn_word=ops.DYN_BS)
+                ops.gemm_resid(lw["router"], self.src["xn"][t], ws["rlog"].shape[2], H, ws["rlog"][t], add_residual=False,
+                               dyn=dt)
+                ops.moe_route(ws["rlog"][t], E, self.top_k, self.norm_topk, ws["wt"][t], ws["active"], ws["elist"],
+                              ws["n_active"], dyn=dt, dyn_word=ops.DYN_BS)
             if self.debug_routing is not None and t == 0:    # tests: the routing weights of every MoE layer
                 self.debug_routing.append((i, ws["wt"][0].clone()))
             mev = self.moe_events if (self.moe_events is not None and self.moe_events[0] == i and t == 0) else None
@@ -467,9 +478,15 @@ class NativeTarget:
         pv = part[:ns * mt * 16 * H].view(ns, mt * 16, H)
         for r in range(R):
             dt, x = dyn[r], xn[r]
-            ops.gemm_resid(lw["router"], ops.rows_frag(x), w["rlog"].shape[2], H, w["rlog"][0], add_residual=False, dyn=dt)
-            ops.moe_route(w["rlog"][0], self.E, self.top_k, self.norm_topk, w["wt"][0], w["active"], w["elist"],
-                          w["n_active"], dyn=dt, dyn_word=ops.DYN_BS)
+            if self.moe_router_fused:   # gate Linear + routing in one launch on the tile's normalised fragments
+                ops.moe_router(h=None, norm_w=None, eps=self.eps, xn=x, wp_router=lw["router"], K=H, E=self.E,
+                               top_k=self.top_k, norm_topk=self.norm_topk, rlog=w["rlog"][0], wt=w["wt"][0],
+                               active=w["active"], lst=w["elist"], n_active=w["n_active"], ticket=w["rticket"], dyn=dt,
+                               dyn_word=ops.DYN_BS)
+            else:
+                ops.gemm_resid(lw["router"], ops.rows_frag(x), w["rlog"].shape[2], H, w["rlog"][0], add_residual=False, dyn=dt)
+                ops.moe_route(w["rlog"][0], self.E, self.top_k, self.norm_topk, w["wt"][0], w["active"], w["elist"],
+                              w["n_active"], dyn=dt, dyn_word=ops.DYN_BS)
             if H <= 2048 and self.moe_pair_kernel:
                 ops.moe_gate_up(lw["gu_e"], x, self.E, self.Ie, H, w["act_e"], w["elist"], w["n_active"], dyn=dt,
                                 valid_word=ops.DYN_BS)

@@ -337,6 +337,16 @@ int dfl_candidate_select(const int64_t *blocks, int64_t blk_stride, const int64_
  *    expert's output and accumulates in bf16: fewer roundings, inside the bf16 tolerance). */
 int dfl_moe_route(const void *logits, int ld, int E, int top_k, int norm_topk, void *wt, int32_t *active, int32_t *list,
                   int32_t *n_active, const int32_t *dyn, int dyn_word, void *stream);
+/* The block's post-attention RMSNorm (Qwen3MoeRMSNorm), the gate Linear and dfl_moe_route in ONE launch (round 4; they are
+ * latency, not bytes: 15 % of a 48-layer verify as three launches).  h != NULL: rows [16][ldh] bf16 are normalised with
+ * norm_w / eps and written to xn_frag (frag16 [K/8][16][8], the expert GEMMs' source; rows >= dyn[dyn_word]: zeros);
+ * h == NULL: xn_frag already holds the normalised rows.  wp_router: the gate weight [E padded to 16][K] packed
+ * (dfl_pack_weight); rlog bf16 [16][ld] receives the logits (ld >= padded E, ld % 8 == 0); wt / active / list / n_active
+ * as dfl_moe_route writes them (same arithmetic).  ticket: one int32, zero before the first launch, left zero by every
+ * launch.  K <= 4096, E even. */
+int dfl_moe_router(const void *h, int64_t ldh, const void *norm_w, float eps, void *xn_frag, const void *wp_router, int K,
+                   int E, int top_k, int norm_topk, void *rlog, int ld, void *wt, int32_t *active, int32_t *list,
+                   int32_t *n_active, const int32_t *dyn, int dyn_word, int32_t *ticket, void *stream);
 int dfl_gemm_silu_mul_experts(const void *wp_gateup, int64_t wp_expert_stride, const dfl_rows *x, int E, int I, int K,
                               void *act_frag, int64_t act_expert_stride, const int32_t *list, const int32_t *n_active,
                               const int32_t *dyn, void *stream);

@@ -85,6 +85,63 @@ def test_moe_route_matches_torch(E, top_k, norm):
     assert k == int(act_ref.sum()) and lst[:k].cpu().tolist() == act_ref.nonzero()[:, 0].tolist()
 
 
+@pytest.mark.parametrize("K,E,top_k,rows,with_norm", [(2048, 128, 8, 16, True), (2048, 128, 8, 5, True), (512, 16, 4, 11, True),
+                                                       (4096, 200, 8, 16, True), (2048, 128, 8, 9, False), (1024, 24, 2, 16, False)])
+def test_moe_router_one_launch_equals_the_three(K, E, top_k, rows, with_norm):
+    """dfl_moe_router (RMSNorm + gate Linear + routing in one launch, the logits handed to the last workgroup through
+    write-through stores) against dfl_norm_pack + dfl_gemm_resid + dfl_moe_route: same fragments, same routing weights,
+    flags, list and count — over repeated launches (the arrival ticket re-arms itself) on changing inputs; the logits
+    agree within the two GEMMs' summation orders and the normalised rows with Qwen3MoeRMSNorm's rounding points."""
+    from dflash_amd import ops
+    g = torch.Generator().manual_seed(K + E + rows)
+    ep = (E + 15) // 16 * 16
+    rw = torch.zeros(ep, K, dtype=BF16)
+    rw[:E] = (torch.randn(E, K, generator=g) * 0.3).to(BF16)
+    wp = ops.pack_weight(rw.to(dev()))
+    nw = (1 + 0.1 * torch.randn(K, generator=g)).to(BF16).to(dev())
+    dyn = torch.zeros(8, dtype=torch.int32, device=dev())
+    ops.set_dyn(dyn, 0, 0, rows, 0)
+    ticket = torch.zeros(1, dtype=torch.int32, device=dev())
+
+    def outs():
+        return dict(wt=torch.full((16, E), 7.0, dtype=BF16, device=dev()), active=torch.full((E,), 9, dtype=torch.int32, device=dev()),
+                    lst=torch.full((E,), -1, dtype=torch.int32, device=dev()), n=torch.zeros(1, dtype=torch.int32, device=dev()),
+                    rlog=torch.zeros(16, ep, dtype=BF16, device=dev()), xn=torch.full((16 * K,), 3.0, dtype=BF16, device=dev()))
+
+    for step in range(3):
+        h = torch.randn(16, K + 64, generator=g).to(BF16).to(dev())[:, :K]      # a row stride wider than K
+        a, b = outs(), outs()
+        ops.norm_pack(norm_w=nw, frag=a["xn"], H=K, eps=1e-6, resid_in=h.contiguous(), dyn=dyn, dyn_word=ops.DYN_BS)
+        if not with_norm:
+            b["xn"].copy_(a["xn"])
+        ops.gemm_resid(wp, ops.rows_frag(a["xn"]), ep, K, a["rlog"], add_residual=False, dyn=dyn)
+        ops.moe_route(a["rlog"], E, top_k, True, a["wt"], a["active"], a["lst"], a["n"], dyn=dyn, dyn_word=ops.DYN_BS)
+        ops.moe_router(h=h if with_norm else None, norm_w=nw if with_norm else None, eps=1e-6, xn=b["xn"], wp_router=wp, K=K, E=E,
+                       top_k=top_k, norm_topk=True, rlog=b["rlog"], wt=b["wt"], active=b["active"], lst=b["lst"], n_active=b["n"],
+                       ticket=ticket, dyn=dyn, dyn_word=ops.DYN_BS)
+        torch.cuda.synchronize()
+        assert int(ticket) == 0
+        if with_norm:    # Qwen3MoeRMSNorm: fp32 normalise, cast to bf16, times weight; absent rows are zero fragments
+            hf = h.float()
+            ref = (nw.float() * (hf * torch.rsqrt(hf.pow(2).mean(-1, keepdim=True) + 1e-6)).to(BF16).float()).to(BF16)
+            ref[rows:] = 0
+            got = b["xn"].view(K // 8, 16, 8).permute(1, 0, 2).reshape(16, K)
+            assert torch.equal(got, ref), step
+        assert torch.equal(a["xn"], b["xn"]), step
+        # the two GEMMs sum K in different orders: bf16 logits may differ by a rounding step
+        d = (a["rlog"][:, :E].float() - b["rlog"][:, :E].float()).abs().max()
+        assert d <= 2 ** -6 * a["rlog"].float().abs().max(), (step, d)
+        # routing of the fused launch == dfl_moe_route applied to ITS logits (exact), and == the split path wherever
+        # the logits are bit-equal (nearly always)
+        c = outs()
+        ops.moe_route(b["rlog"], E, top_k, True, c["wt"], c["active"], c["lst"], c["n"], dyn=dyn, dyn_word=ops.DYN_BS)
+        assert torch.equal(b["wt"], c["wt"]) and torch.equal(b["active"], c["active"]) and int(b["n"]) == int(c["n"]), step
+        k = int(b["n"])
+        assert torch.equal(b["lst"][:k], c["lst"][:k]), step
+        if torch.equal(a["rlog"], b["rlog"]):
+            assert torch.equal(a["wt"], b["wt"]) and torch.equal(a["lst"][:k], b["lst"][:k])
+
+
 @pytest.mark.parametrize("pair_kernel", [False, True])
 def test_grouped_expert_gemms_match_torch(pair_kernel):
     """dfl_gemm_silu_mul_experts + dfl_moe_down against the HF experts loop in fp32 (Qwen3MoeExperts.forward): only the
