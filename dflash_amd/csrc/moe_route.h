@@ -5,6 +5,26 @@
 #pragma once
 #include "dfl_common.h"
 
+// 64-lane max / min, result in every lane: the same DPP steps (round 4: the LDS-routed butterfly they replace cost the
+// MoE router's top-k 96 dependent ~100-cycle steps per row, ~4 us of an 8.7 us launch).  Exact either way.
+__device__ __forceinline__ float route_wave_max(float v) {
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)));
+  const int iv = __builtin_bit_cast(int, v);
+  return fmaxf(fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)), __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16))),
+               fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)), __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48))));
+}
+__device__ __forceinline__ int route_wave_min(int v) {
+  v = min(v, __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true));
+  v = min(v, __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true));
+  v = min(v, __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true));
+  v = min(v, __builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, true));
+  return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+             min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
 __device__ __forceinline__ bool route_better(float v, int i, float ov, int oi) { return v > ov || (v == ov && i < oi); }
 
 // logits_row: the row's E bf16 logits.  On return every lane holds the k selected experts (sel_i, in selection order),
@@ -19,7 +39,7 @@ __device__ __forceinline__ void route_row(const bf16_t *logits_row, int E, int t
     p[j] = e < E ? bf2f(logits_row[e]) : -INFINITY;
     mx = fmaxf(mx, p[j]);
   }
-  mx = wave_max(mx);
+  mx = route_wave_max(mx);
   float sum = 0.f;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -47,8 +67,8 @@ __device__ __forceinline__ void route_row(const bf16_t *logits_row, int E, int t
     }
     // the wave's best: the largest probability, and among the lanes that hold it the lowest expert (two DPP
     // reductions; a NaN row leaves bv = -1 / bi = INT_MAX in every lane, handled below)
-    const float mv = wave_max(bv);
-    bi = wave_min_i32(bv == mv ? bi : 0x7fffffff);
+    const float mv = route_wave_max(bv);
+    bi = route_wave_min(bv == mv ? bi : 0x7fffffff);
     bv = mv;
     if (bi == 0x7fffffff) {  // a NaN row (one NaN logit makes every probability NaN): no comparison succeeded.  The index
       bi = r;                // feeds LDS / global counters downstream (k_pmoe_plan, k_moe_route), so it must stay < E: round
