@@ -2,7 +2,7 @@
 # Round-4 profile set, run on the GPU box (gpurun): rocprofv3 kernel stats of the bench command per workload, FETCH_SIZE /
 # WRITE_SIZE PMC passes (separate runs, kernel trace only), summaries into gpurun_out/r4prof/.  Profiled runs launch
 # eagerly (--eager): same kernels as the replayed cycle, one dispatch record per launch.
-#   profile_r4.sh stats1 | stats4 | statsl | statsm | pmc1 | pmc4 | pmcm | lines
+#   profile_r4.sh stats1 | stats4 | statsl | statsm | pmc1 | pmc4 | pmcm | lines | linem
 set -u
 R=${GRAFT_REPO_ROOT:-$PWD}
 O="$R/gpurun_out/r4prof"
@@ -43,6 +43,10 @@ case "${1:-all}" in
     for rep in 1 2; do for w in 224 64 96; do
       DFL_ATTN_HEAD_WGS=$w python3 bench.py --no-cpu-baseline --no-batch4 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.readline()); print('N=1 attn_head_wgs=$w', round(d['ms_per_step'],4), d['lossless_fraction'])"
     done; done ;;
+  linem)   # BASELINE configs[4]'s line alone
+    cd "$R"
+    python3 bench.py --no-cpu-baseline --workload qwen3-30b-a3b > "$O/r4_bench_qwen3_30b_a3b.json" 2> "$O/r4_bench_moe.err"
+    python3 -c "import json; d=json.loads(open('$O/r4_bench_qwen3_30b_a3b.json').read().strip().splitlines()[-1]); print(round(d['value'],1),'tok/s',round(d['ms_per_step'],4),'ms',d['lossless_fraction'],'tau',round(d['mean_acceptance_length'],2),'roofline frac',round(d['roofline']['frac'],3), d['used_block_sizes'])" ;;
   lines)   # the bench lines kept under profiles/ (un-profiled, replay where the workload allows it)
     cd "$R"
     python3 bench.py > "$O/r4_bench_n1.json" 2> "$O/r4_bench_n1.err"; tail -c 300 "$O/r4_bench_n1.err"

@@ -142,6 +142,49 @@ def test_moe_router_one_launch_equals_the_three(K, E, top_k, rows, with_norm):
             assert torch.equal(a["wt"], b["wt"]) and torch.equal(a["lst"][:k], b["lst"][:k])
 
 
+def test_moe_router_hand_off_under_load():
+    """The logits of dfl_moe_router cross workgroups INSIDE the launch (write-through stores, a returning ticket, sc1
+    loads by the last arriver).  A stale read there shows only under load and with changing data: 300 launches on fresh
+    rows each, while a side stream keeps the memory system busy with large copies; every launch's routing must equal
+    dfl_moe_route applied to the logits the launch left in memory, and the logits must move with the rows."""
+    from dflash_amd import ops
+    K, E, top_k = 2048, 128, 8
+    g = torch.Generator().manual_seed(9)
+    wp = ops.pack_weight((torch.randn(E, K, generator=g) * 0.3).to(BF16).to(dev()))
+    nw = torch.ones(K, dtype=BF16, device=dev())
+    ticket = torch.zeros(1, dtype=torch.int32, device=dev())
+    n_it = 300
+    hs = torch.randn(n_it, 16, K, generator=g).to(BF16).to(dev())
+    xn = torch.zeros(16 * K, dtype=BF16, device=dev())
+    rlog = torch.zeros(n_it, 16, E, dtype=BF16, device=dev())
+    wt = torch.zeros(n_it, 16, E, dtype=BF16, device=dev())
+    active = torch.zeros(E, dtype=torch.int32, device=dev())
+    lst = torch.zeros(E, dtype=torch.int32, device=dev())
+    ns = torch.zeros(n_it, 1, dtype=torch.int32, device=dev())
+    big_a = torch.empty(256 << 20, dtype=torch.uint8, device=dev())
+    big_b = torch.empty_like(big_a)
+    side = torch.cuda.Stream()
+    stop = torch.cuda.Event()
+    with torch.cuda.stream(side):
+        for _ in range(40):
+            big_b.copy_(big_a)
+        stop.record()
+    for i in range(n_it):
+        ops.moe_router(h=hs[i], norm_w=nw, eps=1e-6, xn=xn, wp_router=wp, K=K, E=E, top_k=top_k, norm_topk=True, rlog=rlog[i],
+                       wt=wt[i], active=active, lst=lst, n_active=ns[i], ticket=ticket)
+    busy_at_end = not stop.query()     # (informational: the copies outlasted the launches)
+    torch.cuda.synchronize()
+    assert int(ticket) == 0
+    ref_wt = torch.zeros(16, E, dtype=BF16, device=dev())
+    ref_n = torch.zeros(1, dtype=torch.int32, device=dev())
+    bad = 0
+    for i in range(n_it):
+        ops.moe_route(rlog[i], E, top_k, True, ref_wt, active, lst, ref_n)
+        bad += int(not torch.equal(ref_wt, wt[i])) + int(int(ref_n) != int(ns[i]))
+    assert bad == 0, (bad, busy_at_end)
+    assert len({rlog[i].float().sum().item() for i in range(0, n_it, 37)}) > 5      # the logits follow the rows
+
+
 @pytest.mark.parametrize("pair_kernel", [False, True])
 def test_grouped_expert_gemms_match_torch(pair_kernel):
     """dfl_gemm_silu_mul_experts + dfl_moe_down against the HF experts loop in fp32 (Qwen3MoeExperts.forward): only the
