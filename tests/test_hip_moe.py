@@ -142,6 +142,39 @@ def test_moe_router_one_launch_equals_the_three(K, E, top_k, rows, with_norm):
             assert torch.equal(a["wt"], b["wt"]) and torch.equal(a["lst"][:k], b["lst"][:k])
 
 
+@pytest.mark.parametrize("E,top_k", [(128, 8), (16, 4), (200, 8), (2, 1)])
+def test_moe_route_nan_row_and_edges(E, top_k):
+    """A row of NaN logits (a NaN anywhere upstream makes the whole softmax NaN) must not fault or hang: it routes to
+    experts 0 .. k-1 with NaN weights — the NaN goes on through the expert sums as it does through torch.topk +
+    index_add_ — while the other rows route as always; E = 2 / top-1 and -inf logits are handled too."""
+    from dflash_amd import ops
+    g = torch.Generator().manual_seed(E)
+    ep = (E + 15) // 16 * 16
+    logits = torch.zeros(16, ep, dtype=BF16)
+    logits[:, :E] = _tie_free_logits(16, E, g) if E > 2 else torch.tensor([[0.5, -0.25]] * 16, dtype=BF16)
+    logits[3, :E] = float("nan")
+    if E > 2:
+        logits[5, 1] = float("-inf")     # probability exactly 0: never selected while k others are positive
+    wt = torch.full((16, E), 7.0, dtype=BF16, device=dev())
+    active = torch.zeros(E, dtype=torch.int32, device=dev())
+    lst = torch.zeros(E, dtype=torch.int32, device=dev())
+    n = torch.zeros(1, dtype=torch.int32, device=dev())
+    ops.moe_route(logits.to(dev()), E, top_k, True, wt, active, lst, n)
+    torch.cuda.synchronize()
+    got = wt.float().cpu()
+    assert torch.isnan(got[3, :top_k]).all() and torch.count_nonzero(got[3, top_k:]) == 0
+    for m in (0, 5, 15):
+        p = torch.softmax(logits[m, :E].float(), dim=-1)
+        v, i = torch.topk(p, top_k)
+        ref = torch.zeros(E)
+        ref[i] = (v / v.sum()).to(BF16).float()
+        assert torch.equal(got[m] != 0, ref != 0) and torch.allclose(got[m], ref, rtol=2 ** -7, atol=1e-4), m
+    if E > 2:
+        assert got[5, 1] == 0
+    k = int(n)
+    assert lst[:k].cpu().tolist() == (torch.nan_to_num(got, nan=1.0) != 0).any(dim=0).nonzero()[:, 0].tolist()
+
+
 def test_moe_router_hand_off_under_load():
     """The logits of dfl_moe_router cross workgroups INSIDE the launch (write-through stores, a returning ticket, sc1
     loads by the last arriver).  A stale read there shows only under load and with changing data: 300 launches on fresh
