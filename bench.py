@@ -355,7 +355,8 @@ def single_leg(args, spec, rank, dev, target, draft, cfg, perm, meta):
         t_c = cuda_time()
         chosen = sched.select(cyc[0])
         b = max(1, min(chosen, s.max_length - s.start))
-        r = s.cycle(b)
+        # replay of the size's graph pair (DecodeSession.capture_sizes) unless this cycle carries event pairs
+        r = s.cycle_sized(b) if (allow_graph and not instr) else s.cycle(b)
         sched.update(tau=r.tau, cycle_s=cuda_time() - t_c, effective_bs=b, cycle_idx=cyc[0], l_gen=float(b))
         used.append(b)
         cyc[0] += 1
@@ -364,9 +365,12 @@ def single_leg(args, spec, rank, dev, target, draft, cfg, perm, meta):
     step()       # first steady-state cycle: one-off code-object loads (60 ms) — setup, like cycle 0
     for _ in range(args.warmup):
         step()
-    use_graph = (not args.eager) and sched is None and T < 1e-5 and native and args.attn_impl == "head" and not args.fuse_oproj
-    if use_graph:   # the steady-state cycle as two hipGraph replays (DecodeSession.capture), captured before the timed region
+    use_graph = (not args.eager) and T < 1e-5 and native and args.attn_impl == "head" and not args.fuse_oproj \
+        and (sched is None or (min(sched_c) >= 2 and max(sched_c) <= 16))
+    if use_graph and sched is None:   # the steady-state cycle as two hipGraph replays (DecodeSession.capture), captured before the timed region
         s.capture(bs)
+    elif use_graph:                   # a scheduler picks the size every cycle: one pair of graphs per candidate size, no run-ahead draft
+        s.capture_sizes(sched_c)
 
     ev_all, lm_ev, gu_ev, moe_log = [], [], [], None
     E = max(1, args.event_every)

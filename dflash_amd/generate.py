@@ -450,6 +450,112 @@ class DecodeSession:
         self.stopped = bool(res[2])
         return SimpleNamespace(tau=tau, bs=bs, start=start, stop=self.stopped)
 
+    # ------------------------------------------------------------------ hipGraph replay with a caller-chosen block size
+    @torch.inference_mode()
+    def capture_sizes(self, sizes) -> None:
+        """One pair of hipGraphs per block size in `sizes` (2..16 each) for loops whose caller picks the size every cycle —
+        the policy loop of benchmark_dynamic_schedule.py:319-379: [draft forward + lm_head] and [target verify + accept],
+        every launch taking its lengths from the two device records.  cycle_sized() writes those records from the host's
+        own bookkeeping (two 64-thread launches) and replays the pair; there is no run-ahead draft, since the next block's
+        size is only known once the scheduler has seen this cycle's result.  Call after at least one draft cycle."""
+        sizes = sorted({int(b) for b in sizes})
+        if not (self.native and self.use_draft and sizes and 2 <= sizes[0] and sizes[-1] <= 16 and self.temperature < 1e-5
+                and self.stop_t is None and self.draft_temperature < 1e-5 and self.target.attn_impl == "head"
+                and not self.target.fuse_oproj and getattr(self.model, "attn_impl", "head") == "head"):
+            raise ValueError("capture_sizes needs a NativeTarget ('head' attention), a draft, T = 0, no stop ids, sizes in 2..16")
+        if not self._armed:
+            raise RuntimeError("capture_sizes: run one cycle first")
+        m, t = self.model, self.target
+        bound = min(self.max_length, self.dcache.max_rows - 16 - sizes[-1], self.tcache.max_rows - sizes[-1])
+        if bound < self.start:
+            raise RuntimeError("capture_sizes: the caches leave no room for a replayed cycle")
+        m._rope_tab(bound + 64 + 64)
+        t._rope_tab(bound + 64 + 64)
+        torch.cuda.synchronize(self.dev)
+        tl = self.model.target_layer_ids
+        graphs = {}
+        for bs in sizes:
+            def draft_now(bs=bs):
+                hid = m.draft_block(self.dcache, th_rows=self.taps_buf[:16], tau=16, bs=bs, pos0=bound, block_ids=self.block[0],
+                                    embed=self.embed_w, dyn_ready=True, s_bound=bound)
+                _draft_ids(m, hid, self.lm_wp, bs, self.block[:, :bs], 0.0, self.draft_logits)
+
+            def verify_accept(bs=bs):
+                post, _ = t.verify(self.block[0, :bs], bound, self.tcache, temperature=0.0, tap_layers=tl,
+                                   taps_out=self.taps_buf, dyn_lengths=True)
+                ops.accept_commit(self.block[0, :bs], post[0].contiguous(), bs, self.output_ids[0], self.dyn, None, self.result,
+                                  rearm=(self.block[0], self.max_bs, self.mask_token_id), dyn_t=self.tcache.dyn)
+
+            graphs[bs] = (capture_graph(draft_now), capture_graph(verify_accept))
+        self.tcache.crop(self.start)     # (verify's host-side bookkeeping ran with the bound)
+        self._sgraphs, self._sgraph_bound = graphs, bound
+        self._sgraph_rope = (m._rope[0].data_ptr(), t._rope[0].data_ptr())
+        self._sgraph_keep = (m._rope, t._rope, getattr(m, "ws", None), getattr(t, "ws", None), getattr(t, "_taps", None),
+                             self.lm_wp, self.embed_w, getattr(t, "lm_wp", None))
+
+    def _sized_ok(self, bs: int) -> bool:
+        g = getattr(self, "_sgraphs", None)
+        if not (g and bs in g and self._armed and self.stop_t is None and not self.stop_always
+                and (self.events is None or not self.record_events) and self.target_hidden is not None
+                and self.target_hidden.shape[1] <= 16 and self.start + bs <= min(self.max_length, self._sgraph_bound)):
+            return False
+        m, t = self.model, self.target
+        if m._rope is None or t._rope is None or (m._rope[0].data_ptr(), t._rope[0].data_ptr()) != self._sgraph_rope:
+            self._sgraphs = None         # a replaced RoPE table: the captured launches hold the old one's address
+            return False
+        return True
+
+    @torch.inference_mode()
+    def cycle_sized(self, bs: int, *, after_draft: Optional[Callable] = None) -> SimpleNamespace:
+        """One pass of model/dflash.py:235-268 with the caller's block size by graph replay (capture_sizes); falls back
+        to cycle(bs) where the cycle cannot be replayed (a size that was not captured — the clamped tail —, events being
+        recorded, cycle 0's prompt-length context)."""
+        if not self._sized_ok(bs):
+            return self.cycle(bs, after_draft=after_draft)
+        t_call = time.perf_counter() if self.host_times is not None else 0.0
+        start = self.start
+        tau_c = int(self.target_hidden.shape[1])
+        S = self.dcache.get_seq_length()
+        # the two length records, exactly as the eager launches would write them (model.draft_block, NativeTarget.verify)
+        ops.set_dyn2(self.dcache.dyn, S, tau_c, bs, S)
+        ops.set_dyn2(self.tcache.dyn, start, 0, bs, start)
+        self.tcache._dyn_bs = bs
+        self._ahead = None
+        dg, vg = self._sgraphs[bs]
+        dg.replay()
+        self.dcache.length = S + tau_c
+        blk = self.block[:, :bs]
+        if self.hook is not None:
+            self.hook(blk, start, self.hook_calls)
+        self.hook_calls += 1
+        if after_draft is not None:
+            after_draft(blk)
+        if self.poll_result:
+            self._res_np[3] = -1
+        vg.replay()
+        self._armed = True
+        self._dyn_bs = bs
+        t_enq = time.perf_counter() if self.host_times is not None else 0.0
+        if self.poll_result:
+            t0 = time.perf_counter()
+            while self._res_np[3] == -1:
+                if time.perf_counter() - t0 > 0.05:
+                    torch.cuda.current_stream().synchronize()
+                    if self._res_np[3] == -1:
+                        raise RuntimeError("dfl_accept_commit: the result never arrived in host memory")
+            res = self._res_np.tolist()
+        else:
+            res = self.result.tolist()
+        if self.host_times is not None:
+            self.host_times.append((t_enq - t_call, time.perf_counter() - t_enq))
+        tau = res[0] + 1
+        self.start = start + tau
+        self.tcache.length = start + bs
+        self.tcache.crop(self.start)
+        self.target_hidden = self.taps_buf[None, :tau]
+        self.stopped = bool(res[2])
+        return SimpleNamespace(tau=tau, bs=bs, start=start, stop=self.stopped)
+
     def finish(self) -> torch.Tensor:
         return _trim(self.output_ids, self.max_length, self.mask_token_id, self.stop_token_ids, self.n_in)
 
@@ -515,8 +621,16 @@ def run_decode(model, target, input_ids: torch.Tensor, *, mask_token_id: int, ma
             # (collect_profile: no run-ahead draft — its event pairs would be recorded during cycle N and handed to
             # cycle N + 1, outside that cycle's [cycle0, cycle1] marks; benchmark.py:149-160 times each phase inside its
             # own cycle)
-            r = s.cycle(bs, draft_steps=draft_steps, want_hidden=want_hidden, after_draft=after_draft,
-                        ahead_ok=scheduler is None and draft_steps == 1 and not collect_profile)
+            if (use_graphs and scheduler is not None and draft_steps == 1 and not collect_profile and want_hidden
+                    and not draft_prefill and s.stop_t is None and temperature < 1e-5 and draft_temperature < 1e-5
+                    and 2 <= min(scheduler.candidates) and max(scheduler.candidates) <= 16):
+                # the policy loop by replay: one pair of graphs per candidate size (DecodeSession.capture_sizes)
+                if getattr(s, "_sgraphs", None) is None and s._armed:
+                    s.capture_sizes(scheduler.candidates)
+                r = s.cycle_sized(bs, after_draft=after_draft)
+            else:
+                r = s.cycle(bs, draft_steps=draft_steps, want_hidden=want_hidden, after_draft=after_draft,
+                            ahead_ok=scheduler is None and draft_steps == 1 and not collect_profile)
         taus.append(r.tau)
         used_bs.append(bs)
         lgens.append(lg[0])

@@ -1097,3 +1097,102 @@ def test_generate_loop_with_graph_replay_env(monkeypatch):
         assert r.output_ids[0].tolist() == G[:33 + n_new].tolist(), mode
         runs[mode] = r
     assert runs["0"].acceptance_lengths == runs["1"].acceptance_lengths
+
+
+class _ScriptedSizes:
+    """A scheduler with the attributes run_decode's cycle trace reads (dflash_amd/scheduler.py) that walks a fixed list of
+    block sizes: the measured cycle time cannot change what the two runs of a test do."""
+
+    def __init__(self, sizes, candidates):
+        self.sizes, self.candidates = list(sizes), sorted(candidates)
+        self.current = self.candidates[-1]
+        self.tau_hat = dict.fromkeys(self.candidates)
+        self.cycle_hat = dict.fromkeys(self.candidates)
+        self.score_hat = dict.fromkeys(self.candidates)
+        self.adl_lgen_hat = self.adl_lacc_hat = None
+        self.adl_target_k = self.adl_target_bs = self.candidates[-1]
+        self.seen = []
+
+    def select(self, cyc):
+        self.current = self.sizes[cyc % len(self.sizes)]
+        return self.current
+
+    def update(self, **kw):
+        self.seen.append((kw["effective_bs"], kw["tau"]))
+
+
+def test_policy_loop_by_graph_replay_equals_the_eager_policy_loop(monkeypatch):
+    """The dynamic-schedule loop (benchmark_dynamic_schedule.py:319-379) with one pair of hipGraphs per candidate size
+    (DecodeSession.capture_sizes / cycle_sized; DFL_GRAPH=1): ids, acceptance lengths and the sizes used equal the eager
+    loop's, through size changes every cycle, the clamped tail (sizes that were never captured) and cycle 0."""
+    from dflash_amd import NativeTarget
+    from dflash_amd.generate import dflash_generate_policy
+    from dflash_amd.synthetic import greedy_walk, impose_greedy_walk
+    cfg = H.tiny_cfg()
+    hf = _tiny_hf()
+    perm = impose_greedy_walk(hf, seed=6)
+    prompt = torch.randint(0, 2000, (1, 37), generator=torch.Generator().manual_seed(8)).to(dev())
+    n_new = 171
+    G = greedy_walk(perm, prompt, n_new + 40).to(dev())
+    plan = H.make_plan(96, 16, 23)
+
+    def hook(blk, start, call):
+        k = min(plan[call], blk.shape[1] - 1)
+        blk[0, 1:k + 1] = G[start + 1:start + k + 1]
+        if k + 1 < blk.shape[1]:
+            blk[0, k + 1] = (G[start + k + 1] + 1) % 2000
+
+    sizes = [16, 8, 12, 12, 16, 8, 8, 12]
+    runs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("DFL_GRAPH", mode)
+        sched = _ScriptedSizes(sizes, (8, 12, 16))
+        r = dflash_generate_policy(model=make_model(cfg), target=NativeTarget(hf), input_ids=prompt,
+                                   mask_token_id=cfg.mask_token_id, max_new_tokens=n_new, stop_token_ids=None, temperature=0.0,
+                                   scheduler=sched, draft_token_hook=hook)
+        assert r.output_ids[0].tolist() == G[:37 + n_new].tolist(), mode
+        runs[mode] = (r, sched)
+    a, b = runs["0"], runs["1"]
+    assert a[0].acceptance_lengths == b[0].acceptance_lengths and a[0].used_block_sizes == b[0].used_block_sizes
+    assert a[1].seen == b[1].seen and len(set(a[0].used_block_sizes)) >= 3
+
+
+def test_cycle_sized_replays_and_falls_back():
+    """DecodeSession.cycle_sized: replayed for captured sizes, eager for the others (and when events are recorded), and a
+    session may go back and forth between cycle(), cycle_sized() and sizes freely."""
+    from dflash_amd import NativeTarget
+    from dflash_amd.generate import DecodeSession
+    from dflash_amd.synthetic import greedy_walk, impose_greedy_walk
+    cfg = H.tiny_cfg()
+    hf = _tiny_hf()
+    perm = impose_greedy_walk(hf, seed=9)
+    prompt = torch.randint(0, 2000, (1, 29), generator=torch.Generator().manual_seed(5)).to(dev())
+    n_new = 160
+    G = greedy_walk(perm, prompt, n_new + 40).to(dev())
+    plan = H.make_plan(96, 16, 31)
+
+    def hook(blk, start, call):
+        k = min(plan[call], blk.shape[1] - 1)
+        blk[0, 1:k + 1] = G[start + 1:start + k + 1]
+        if k + 1 < blk.shape[1]:
+            blk[0, k + 1] = (G[start + k + 1] + 1) % 2000
+
+    s = DecodeSession(make_model(cfg), NativeTarget(hf), prompt, mask_token_id=cfg.mask_token_id, max_new_tokens=n_new,
+                      max_block_size=16, stop_token_ids=None, temperature=0.0, draft_token_hook=hook)
+    s.prefill()
+    s.cycle(16)
+    s.capture_sizes((8, 16))
+    seq = [16, 8, 10, 16, 16, 8, 5, 8, 16, 12, 8]      # 10, 5, 12 were not captured: eager
+    replayed, i, taus = 0, 0, []
+    while s.start < s.max_length:
+        bs = min(seq[i % len(seq)], s.max_length - s.start)
+        if i % 4 == 3:
+            r = s.cycle(bs)                        # an eager cycle in between
+        else:
+            replayed += int(s._sized_ok(bs))
+            r = s.cycle_sized(bs)
+        taus.append(r.tau)
+        assert 1 <= r.tau <= bs
+        i += 1
+    assert s.finish()[0].tolist() == G[:29 + n_new].tolist()
+    assert replayed >= 8, replayed
