@@ -14,6 +14,7 @@
 #include "gemm_rows.h"
 #include "moe_route.h"
 #include <limits.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -342,11 +343,15 @@ struct MoeDownArgs {
   int ldo;
 };
 
-__global__ __launch_bounds__(1024) void k_moe_down(MoeDownArgs a) {
-  __shared__ float red[16][256];
+// CT: column tiles per workgroup.  With CT = 1 every workgroup re-reads every expert's activations (24 KB per expert
+// at I = 768: as many bytes from L2 as weight bytes from HBM); CT = 2 shares an item's activation fragments between two
+// column tiles.
+template <int CT, int NW>
+__global__ __launch_bounds__(NW * 64) void k_moe_down(MoeDownArgs a) {
+  __shared__ float red[NW][CT][256];
   const int tid = threadIdx.x;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
-  const int t = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
+  const int t0 = blockIdx.x * CT, split = blockIdx.y, nsplit = gridDim.y;
   const int n = *a.n_active;
   const int per = (n + nsplit - 1) / nsplit;
   const int p0 = split * per, p1 = min(n, p0 + per);
@@ -356,13 +361,15 @@ __global__ __launch_bounds__(1024) void k_moe_down(MoeDownArgs a) {
   // of 3 serial round trips, 4.7 TB/s at 82 active experts.)
   const int cpe = (a.KSe + 3) >> 2;
   const int nitems = (p1 > p0 ? p1 - p0 : 0) * cpe;
-  f32x4 total = {0.f, 0.f, 0.f, 0.f};
-  bf16x8 wA[4], xA[4], wB[4], xB[4];
+  f32x4 total[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) total[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bf16x8 wA[CT][4], xA[4], wB[CT][4], xB[4];
   bf16_t rA = 0, rB = 0;  // (kept as loaded: converting at the load would make the wave wait for it there)
   // Every request in the loop is UNCONDITIONAL — past the wave's last item a dummy (empty descriptors: zeros, no
   // traffic): behind `if (more) issue` hipcc cannot count the loads in flight and waits vmcnt(0) before the MFMAs of
   // the current item, i.e. for the item it has just requested.
-  auto issue = [&](bf16x8(&wv)[4], bf16x8(&xv)[4], bf16_t &wr, int it) {
+  auto issue = [&](bf16x8(&wv)[CT][4], bf16x8(&xv)[4], bf16_t &wr, int it) {
     const bool live = it < nitems;
     it = live ? it : nitems - 1;
     const int e = a.list[p0 + it / cpe], ks0 = (it % cpe) * 4;
@@ -370,40 +377,46 @@ __global__ __launch_bounds__(1024) void k_moe_down(MoeDownArgs a) {
     // (scalar: a clamp compiled to v_med3 puts the buffer descriptors in VGPRs and every load into a waterfall loop)
     nf = __builtin_amdgcn_readfirstlane(live ? (nf > 4 ? 4 : nf) : 0);
     wr = a.wt[(int64_t)(l & 15) * a.E + e];  // the routing weight of this lane's row; first: loads return in order
-    load_ksteps<4, 0>(xv, a.act + e * a.act_stride + (size_t)ks0 * 64, nf, l);  // re-read by every column tile: L2
-    load_ksteps<4>(wv, a.wd + e * a.wd_stride + ((size_t)t * a.KSe + ks0) * 64, nf, l);  // past nf: zero fragments
-  };
-  auto consume = [&](const bf16x8(&wv)[4], const bf16x8(&xv)[4], bf16_t wraw) {
-    const float wr = bf2f(wraw);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    load_ksteps<4, 0>(xv, a.act + e * a.act_stride + (size_t)ks0 * 64, nf, l);  // re-read by every column group: L2
 #pragma unroll
-    for (int f = 0; f < 4; ++f) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[f], xv[f], acc, 0, 0, 0);
-    // D layout: lane L, register r = output column 4 (L >> 4) + r of row L & 15
-    total += acc * wr;
+    for (int c = 0; c < CT; ++c)
+      load_ksteps<4>(wv[c], a.wd + e * a.wd_stride + ((size_t)(t0 + c) * a.KSe + ks0) * 64, nf, l);  // past nf: zero fragments
+  };
+  auto consume = [&](const bf16x8(&wv)[CT][4], const bf16x8(&xv)[4], bf16_t wraw) {
+    const float wr = bf2f(wraw);
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int f = 0; f < 4; ++f) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[c][f], xv[f], acc, 0, 0, 0);
+      // D layout: lane L, register r = output column 4 (L >> 4) + r of row L & 15
+      total[c] += acc * wr;
+    }
   };
   int it = w;
   if (it < nitems) {
     issue(wA, xA, rA, it);
-    for (; it < nitems; it += 32) {
-      issue(wB, xB, rB, it + 16);
+    for (; it < nitems; it += 2 * NW) {
+      issue(wB, xB, rB, it + NW);
       __builtin_amdgcn_sched_barrier(0);  // (or hipcc sinks the requests below the current item's waits and MFMAs)
       consume(wA, xA, rA);
       __builtin_amdgcn_sched_barrier(0);
-      issue(wA, xA, rA, it + 32);
+      issue(wA, xA, rA, it + 2 * NW);
       __builtin_amdgcn_sched_barrier(0);
-      if (it + 16 < nitems) consume(wB, xB, rB);
+      if (it + NW < nitems) consume(wB, xB, rB);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  *reinterpret_cast<f32x4 *>(&red[w][l * 4]) = total;
+#pragma unroll
+  for (int c = 0; c < CT; ++c) *reinterpret_cast<f32x4 *>(&red[w][c][l * 4]) = total[c];
   __syncthreads();
-  if (tid < 256) {
-    const int m = tid >> 4, nl = tid & 15;
+  for (int o = tid; o < 256 * CT; o += NW * 64) {
+    const int c = o >> 8, m = (o >> 4) & 15, nl = o & 15;
     const int idx = 4 * (m + 16 * (nl >> 2)) + (nl & 3);
     float s = 0.f;
 #pragma unroll
-    for (int ww = 0; ww < 16; ++ww) s += red[ww][idx];
-    a.out[((size_t)split * 16 + m) * a.ldo + t * 16 + nl] = s;
+    for (int ww = 0; ww < NW; ++ww) s += red[ww][c][idx];
+    a.out[((size_t)split * 16 + m) * a.ldo + (t0 + c) * 16 + nl] = s;
   }
 }
 
@@ -598,7 +611,15 @@ extern "C" int dfl_moe_down(const void *wp_down, int64_t wp_expert_stride, const
   a.ntiles = N / 16;
   a.out = out;
   a.ldo = N;
-  hipLaunchKernelGGL(k_moe_down, dim3(N / 16, nsplit), dim3(1024), 0, (hipStream_t)stream, a);
+  // Two column tiles per workgroup share an item's activation fragments (the caller asks for four shares, so that the
+  // grid stays at 256 workgroups for N = 2048); DFL_MOE_DOWN_CT=1: one tile per workgroup, the round-2/3 form
+  // (same box, BASELINE configs[4]'s cycle: one tile 6.44 - 6.45 ms, two 6.34, four tiles on 8 waves 6.37 - 6.38:
+  // profiles/r4_moe_router_ab.txt)
+  static const int ct = [] { const char *e = getenv("DFL_MOE_DOWN_CT"); return e ? atoi(e) : 2; }();
+  if (ct == 2 && N % 32 == 0)
+    hipLaunchKernelGGL((k_moe_down<2, 16>), dim3(N / 32, nsplit), dim3(1024), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL((k_moe_down<1, 16>), dim3(N / 16, nsplit), dim3(1024), 0, (hipStream_t)stream, a);
   DFL_CHECK_LAUNCH("dfl_moe_down");
   return DFL_OK;
 }

@@ -212,7 +212,8 @@ class NativeTarget:
         self.is_moe = any("gu_e" in lw for lw in self.layers)
         if self.is_moe:
             ep = (self.E + 15) // 16 * 16
-            self.moe_nsplit = 2
+            # shares of the active experts (grid.y of dfl_moe_down): 4 with its two-tiles-per-workgroup form (the default)
+            self.moe_nsplit = 2 if (os.environ.get("DFL_MOE_DOWN_CT") == "1" or self.H % 32) else 4
             self.ws.update(xn=z(NT, 16 * self.H), xn1=z(NT, 16 * self.H), rlog=z(NT, 16, ep), wt=z(NT, 16, self.E),
                            act_e=z(self.E, 16 * self.Ie), moe_part=z(self.moe_nsplit, 16, self.H, dt=torch.float32),
                            active=torch.zeros(self.E, dtype=torch.int32, device=dev),
