@@ -280,11 +280,16 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &a) {
     if (!CHUNKED || c == a.nch - 1) finish(t, pos);
   };
 
+  // item 0 of this workgroup (F32 / ARGMAX / RESID): whole tile blockIdx.x, or — a launch cut entirely in halves
+  // (plan_tiles: at most 128 tiles) — half blockIdx.x & 1 of tile blockIdx.x >> 1
+  const int first_tile = (SILU || nwhole > 0) ? (int)blockIdx.x : a.ntiles + ((int)blockIdx.x >> 1);
+  const int first_half = (SILU || nwhole > 0) ? -1 : myhalf;
+  const bool first_live = SILU ? (int)blockIdx.x < ngroups : (nwhole > 0 || has_half);
   // the residual value of this thread's element of the FIRST tile (every thread asks: ff = tid & 255 — no branch)
   auto ask_resid0 = [&]() {
     if (PREF) {
       const int ff = tid & 255;
-      resid0 = a.h_io[(int64_t)(ff >> 4) * a.ldh + (int)blockIdx.x * 16 + (ff & 15)];
+      resid0 = a.h_io[(int64_t)(ff >> 4) * a.ldh + first_tile * 16 + (ff & 15)];
     }
   };
 
@@ -355,8 +360,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &a) {
     // activations past the share are zero as well.  (The expert list of an MoE launch is a dependent scalar load: that
     // launch asks for its first weights once it knows the tile.)
     if (!moe)
-      load_ksteps<FR>(wA, a.wp + ((size_t)(SILU ? 2 * blockIdx.x : blockIdx.x) * a.KS + ks0_of(0)) * 64,
-                      (int)blockIdx.x < ngroups ? nf0 : 0, l);  // (the host cuts tiles in halves only behind whole ones)
+      load_ksteps<FR>(wA, a.wp + ((size_t)(SILU ? 2 * blockIdx.x : first_tile) * a.KS + ks0_of(0)) * 64,
+                      first_live ? nf0 : 0, l, first_half);
     else if (nitems > 0)
       load_ksteps<FR>(wA, a.wp + ((size_t)tile_of(0) * a.KS + ks0_of(0)) * 64, nf0, l);
     GSTAMP(6);
@@ -411,7 +416,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &a) {
   } else {
     // chunked kernels build their activation fragments per item: item 0's behind the weights already requested
     if (nitems > 0 || !moe)
-      load_ksteps<FR>(wA, a.wp + ((size_t)blockIdx.x * a.KS + ks0_of(0)) * 64, (int)blockIdx.x < ngroups ? nf0 : 0, l);
+      load_ksteps<FR>(wA, a.wp + ((size_t)first_tile * a.KS + ks0_of(0)) * 64, first_live ? nf0 : 0, l, first_half);
     GSTAMP(6);
     load_item_x(xA, 0);
     ask_resid0();
@@ -590,6 +595,16 @@ static void plan_tiles(GemmArgs &a, int ntiles, bool allow_half, int &gx) {
   a.ntiles = ntiles;
   a.nhalf = 0;
   const int r = ntiles % 256;
+  // (round 4) at most 128 tiles: ALL of them in halves, one per workgroup — twice the CUs stream half the bytes each
+  // (o_proj / down_proj of a hidden-2048 model: 128 workgroups of one 16-column tile were half the chip).
+  // DFL_HALF_SMALL=0: whole tiles, the round-3 plan.
+  static const bool half_small = [] { const char *e = getenv("DFL_HALF_SMALL"); return !(e && e[0] == '0'); }();
+  if (allow_half && half_small && ntiles <= 128) {
+    gx = 2 * ntiles;
+    a.ntiles = 0;
+    a.nhalf = 2 * ntiles;
+    return;
+  }
   if (!allow_half || ntiles <= 256 || r == 0 || r > 128) return;
   gx = 256;
   a.ntiles = ntiles - r;

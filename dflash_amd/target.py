@@ -692,8 +692,10 @@ class NativeTarget:
                                max_splits=self.max_splits, out_frag=ws["attn"][0], causal=True)
             for t, dt in tiles:
                 if not fuse_o:
+                    # (an MoE block normalises its rows itself — dfl_moe_router: no partial sums of squares wanted, and
+                    # without them a narrow o_proj may run in half tiles on twice the workgroups)
                     ops.gemm_resid(lw["o"], src["attn"][t], H, self.q_dim, hrow[t], add_residual=True,
-                                   ss_out=ws["ss_h"][t], dyn=dt)
+                                   ss_out=None if "gu_e" in lw else ws["ss_h"][t], dyn=dt)
             # every slot j with tap_layers[j] == i: build_target_layer_ids repeats layers for shallow
             # targets and the reference concatenates the same state twice (model/utils.py:16-25)
             sl = [j for j, l in enumerate(tap_layers) if l == i]
