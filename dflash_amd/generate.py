@@ -577,7 +577,7 @@ def run_decode(model, target, input_ids: torch.Tensor, *, mask_token_id: int, ma
     decode_start = cuda_time()
     taus, used_bs, cycle_trace, lgens = [], [], [], []
     draft_prefill = True
-    use_graphs = os.environ.get("DFL_GRAPH", "0") == "1" and s.native and getattr(target, "attn_impl", "") == "head" \
+    use_graphs = os.environ.get("DFL_GRAPH", "1") != "0" and s.native and getattr(target, "attn_impl", "") == "head" \
         and not getattr(target, "fuse_oproj", False)
     cyc = 0
     while s.start < s.max_length:
@@ -609,13 +609,16 @@ def run_decode(model, target, input_ids: torch.Tensor, *, mask_token_id: int, ma
         want_hidden = s.use_draft if (scheduler is not None or not clamp_tail) else bs > 1
         gen_before = s.start - s.n_in
         start_idx = s.start
-        # DFL_GRAPH=1: fixed-size loops replay their steady-state cycles from two hipGraphs (DecodeSession.capture): the
-        # host's share of a cycle drops from ~2.3 ms to ~0.2 ms, the cycle itself is ~3 % longer
+        # fixed-size loops replay their steady-state cycles from two hipGraphs (DecodeSession.capture): the host's share
+        # of a cycle drops from ~2.3 ms to ~0.2 ms at the same GPU time; DFL_GRAPH=0: eager launches
         if (use_graphs and scheduler is None and draft_steps == 1 and not collect_profile and bs == block_size
                 and 2 <= bs <= 16 and want_hidden and not draft_prefill and s._ahead == bs and s.stop_t is None
                 and temperature < 1e-5 and draft_temperature < 1e-5):
-            if getattr(s, "_graph_bs", None) is None:
-                s.capture(bs)
+            if getattr(s, "_graph_bs", None) is None and not getattr(s, "_graph_off", False):
+                try:
+                    s.capture(bs)
+                except (ValueError, RuntimeError):       # a session the graphs do not cover: eager cycles, as before
+                    s._graph_off = True
             r = s.cycle_graph(bs)
         else:
             # (collect_profile: no run-ahead draft — its event pairs would be recorded during cycle N and handed to
@@ -623,10 +626,14 @@ def run_decode(model, target, input_ids: torch.Tensor, *, mask_token_id: int, ma
             # own cycle)
             if (use_graphs and scheduler is not None and draft_steps == 1 and not collect_profile and want_hidden
                     and not draft_prefill and s.stop_t is None and temperature < 1e-5 and draft_temperature < 1e-5
+                    and len(getattr(scheduler, "candidates", ())) > 0
                     and 2 <= min(scheduler.candidates) and max(scheduler.candidates) <= 16):
                 # the policy loop by replay: one pair of graphs per candidate size (DecodeSession.capture_sizes)
-                if getattr(s, "_sgraphs", None) is None and s._armed:
-                    s.capture_sizes(scheduler.candidates)
+                if getattr(s, "_sgraphs", None) is None and s._armed and not getattr(s, "_sgraphs_off", False):
+                    try:
+                        s.capture_sizes(scheduler.candidates)
+                    except (ValueError, RuntimeError):   # a session the graphs do not cover: eager cycles, as before
+                        s._sgraphs_off = True
                 r = s.cycle_sized(bs, after_draft=after_draft)
             else:
                 r = s.cycle(bs, draft_steps=draft_steps, want_hidden=want_hidden, after_draft=after_draft,
@@ -770,6 +777,7 @@ class _Fixed:
 
     def __init__(self, bs):
         self.bs = bs
+        self.candidates = (bs,)
         self.current = self.adl_target_k = self.adl_target_bs = bs
 
     def select(self, cyc):
